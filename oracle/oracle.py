@@ -1,0 +1,248 @@
+"""TEST INFRASTRUCTURE — ctypes loader for the CPU oracle (oracle/g16_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (zksnark-finalproject_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libg16oracle.so")
+_lib = None
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    src_newer = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("g16_oracle.c", "fp_tmpl.h", "ec_tmpl.h", "Makefile"))
+    if force or src_newer:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class _Pk(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query",
+                                          "a_inf", "b1_inf", "b2_inf", "h_inf", "l_inf")] + \
+               [(n, C.c_size_t) for n in ("n_a", "n_b1", "n_b2", "n_h", "n_l")] + \
+               [(n, C.c_void_p) for n in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_banner.restype = C.c_char_p
+        L.orc_set_threads.argtypes = [C.c_int]
+        for f in ("fr", "fq"):
+            for op in ("add", "sub", "mul"):
+                getattr(L, "orc_%s_%s" % (f, op)).argtypes = [u64p, u64p, u64p]
+            getattr(L, "orc_%s_inv" % f).argtypes = [u64p, u64p]
+            getattr(L, "orc_%s_from_canonical" % f).argtypes = [u64p, u64p, C.c_size_t]
+            getattr(L, "orc_%s_to_canonical" % f).argtypes = [u64p, u64p, C.c_size_t]
+        L.orc_fq2_mul.argtypes = [u64p, u64p, u64p]
+        L.orc_fq2_sqr.argtypes = [u64p, u64p]
+        L.orc_fq2_inv.argtypes = [u64p, u64p]
+        for g in ("g1", "g2"):
+            getattr(L, "orc_%s_add" % g).argtypes = [u64p, C.c_int, u64p, C.c_int, u64p, u8p]
+            getattr(L, "orc_%s_mul" % g).argtypes = [u64p, C.c_int, u64p, u64p, u8p]
+            getattr(L, "orc_%s_on_curve" % g).argtypes = [u64p]
+            getattr(L, "orc_msm_%s" % g).argtypes = [u64p, C.c_void_p, u64p, C.c_size_t, u64p, u8p]
+            getattr(L, "orc_fixed_base_%s" % g).argtypes = [u64p, u64p, C.c_size_t, u64p, C.c_void_p]
+        L.orc_ntt.argtypes = [u64p, C.c_uint, C.c_int, C.c_int]
+        csr = [u64p, u32p, u64p] * 3
+        L.orc_witness_map.argtypes = csr + [C.c_size_t, C.c_size_t, u64p, u64p, C.c_uint]
+        L.orc_setup_logs.argtypes = csr + [C.c_size_t, C.c_size_t, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]
+        L.orc_prove.argtypes = [C.POINTER(_Pk), u64p, u64p] + csr + [C.c_size_t, C.c_size_t, u64p, C.c_size_t,
+                                                                     u64p, u8p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _u64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a if shape is None else a.reshape(shape)
+
+
+def set_threads(n):
+    return lib().orc_set_threads(int(n))
+
+
+def fr_from_canonical(a):
+    a = _u64(a).reshape(-1, 4)
+    o = np.empty_like(a)
+    lib().orc_fr_from_canonical(a, o, a.shape[0])
+    return o
+
+
+def fr_to_canonical(a):
+    a = _u64(a).reshape(-1, 4)
+    o = np.empty_like(a)
+    lib().orc_fr_to_canonical(a, o, a.shape[0])
+    return o
+
+
+def fq_from_canonical(a):
+    a = _u64(a).reshape(-1, 6)
+    o = np.empty_like(a)
+    lib().orc_fq_from_canonical(a, o, a.shape[0])
+    return o
+
+
+def fq_to_canonical(a):
+    a = _u64(a).reshape(-1, 6)
+    o = np.empty_like(a)
+    lib().orc_fq_to_canonical(a, o, a.shape[0])
+    return o
+
+
+def binop(name, a, b):
+    a, b = _u64(a), _u64(b)
+    o = np.empty_like(a)
+    getattr(lib(), "orc_" + name)(a, b, o)
+    return o
+
+
+def unop(name, a):
+    a = _u64(a)
+    o = np.empty_like(a)
+    getattr(lib(), "orc_" + name)(a, o)
+    return o
+
+
+def ntt(data, inverse=False, coset=False):
+    """data: (N,4) u64 Montgomery; returns a transformed copy."""
+    d = _u64(data).reshape(-1, 4).copy()
+    n = d.shape[0]
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    rc = lib().orc_ntt(d, log_n, int(inverse), int(coset))
+    assert rc == 0
+    return d
+
+
+def _infptr(inf):
+    if inf is None:
+        return None, None
+    inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    return inf, inf.ctypes.data
+
+
+def msm(group, bases, scalars_canonical, inf=None):
+    """group 'g1'/'g2'; bases (n, 12|24) u64; scalars (n,4) canonical -> (affine limbs, inf flag)"""
+    w = 12 if group == "g1" else 24
+    bases = _u64(bases).reshape(-1, w)
+    sc = _u64(scalars_canonical).reshape(-1, 4)
+    n = min(bases.shape[0], sc.shape[0])
+    keep, ptr = _infptr(inf)
+    out = np.zeros(w, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    if n == 0:
+        bases = np.zeros((1, w), dtype=np.uint64)
+        sc = np.zeros((1, 4), dtype=np.uint64)
+    rc = getattr(lib(), "orc_msm_" + group)(bases, ptr, sc, n, out, oinf)
+    assert rc == 0
+    return out, int(oinf[0])
+
+
+def fixed_base(group, g, scalars_canonical):
+    w = 12 if group == "g1" else 24
+    sc = _u64(scalars_canonical).reshape(-1, 4)
+    n = sc.shape[0]
+    out = np.zeros((n, w), dtype=np.uint64)
+    oinf = np.zeros(n, dtype=np.uint8)
+    rc = getattr(lib(), "orc_fixed_base_" + group)(_u64(g), sc, n, out, oinf.ctypes.data)
+    assert rc == 0
+    return out, oinf
+
+
+def point_mul(group, p, k_canonical, pinf=0):
+    w = 12 if group == "g1" else 24
+    out = np.zeros(w, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    getattr(lib(), "orc_%s_mul" % group)(_u64(p), int(pinf), _u64(k_canonical), out, oinf)
+    return out, int(oinf[0])
+
+
+def point_add(group, p, q, pinf=0, qinf=0):
+    w = 12 if group == "g1" else 24
+    out = np.zeros(w, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    getattr(lib(), "orc_%s_add" % group)(_u64(p), int(pinf), _u64(q), int(qinf), out, oinf)
+    return out, int(oinf[0])
+
+
+def _csr_args(r1cs):
+    args = []
+    for m in ("a", "b", "c"):
+        rp, col, cf = r1cs[m]
+        args += [_u64(rp), np.ascontiguousarray(col, dtype=np.uint32), _u64(cf).reshape(-1, 4)]
+    return args
+
+
+def witness_map(r1cs, z):
+    """r1cs: dict(a=(row_ptr, col, coeff), b=..., c=..., num_inputs, num_constraints); z (n,4) Montgomery."""
+    ni, nc = r1cs["num_inputs"], r1cs["num_constraints"]
+    log_n = max(nc + ni - 1, 0).bit_length()
+    h = np.zeros((1 << log_n, 4), dtype=np.uint64)
+    rc = lib().orc_witness_map(*_csr_args(r1cs), ni, nc, _u64(z).reshape(-1, 4), h, log_n)
+    assert rc == 0, rc
+    return h
+
+
+def setup_logs(r1cs, num_vars, trap_mont):
+    """-> dict of Montgomery Fr arrays: a, b (num_vars), l (num_vars-ni), h (N-1), gabc (ni)."""
+    ni, nc = r1cs["num_inputs"], r1cs["num_constraints"]
+    log_n = max(nc + ni - 1, 0).bit_length()
+    N = 1 << log_n
+    out = dict(a=np.zeros((num_vars, 4), np.uint64), b=np.zeros((num_vars, 4), np.uint64),
+               l=np.zeros((max(num_vars - ni, 1), 4), np.uint64), h=np.zeros((max(N - 1, 1), 4), np.uint64),
+               gabc=np.zeros((ni, 4), np.uint64))
+    rc = lib().orc_setup_logs(*_csr_args(r1cs), ni, nc, num_vars, _u64(trap_mont).reshape(5, 4),
+                              out["a"], out["b"], out["l"], out["h"], out["gabc"])
+    assert rc == 0, rc
+    out["l"] = out["l"][:num_vars - ni]
+    out["h"] = out["h"][:N - 1]
+    out["N"] = N
+    return out
+
+
+def prove(pk, r_mont, s_mont, r1cs, z):
+    """pk: dict with a_query,b_g1_query,b_g2_query,h_query,l_query (+ optional *_inf), alpha_g1,... (u64 arrays)
+       -> (proof 48 u64 = A|B|C affine Montgomery, inf flags[3])"""
+    keep = []
+
+    def ptr(a, dt=np.uint64):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    s = _Pk()
+    for k in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query", "alpha_g1", "beta_g1", "beta_g2",
+              "delta_g1", "delta_g2"):
+        setattr(s, k, ptr(pk[k]))
+    for k, kk in (("a_inf", "a_inf"), ("b1_inf", "b_g1_inf"), ("b2_inf", "b_g2_inf"), ("h_inf", "h_inf"),
+                  ("l_inf", "l_inf")):
+        setattr(s, k, ptr(pk.get(kk), np.uint8))
+    s.n_a = np.asarray(pk["a_query"]).reshape(-1, 12).shape[0]
+    s.n_b1 = np.asarray(pk["b_g1_query"]).reshape(-1, 12).shape[0]
+    s.n_b2 = np.asarray(pk["b_g2_query"]).reshape(-1, 24).shape[0]
+    s.n_h = np.asarray(pk["h_query"]).reshape(-1, 12).shape[0]
+    s.n_l = np.asarray(pk["l_query"]).reshape(-1, 12).shape[0]
+    z = _u64(z).reshape(-1, 4)
+    proof = np.zeros(48, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    rc = lib().orc_prove(C.byref(s), _u64(r_mont), _u64(s_mont), *_csr_args(r1cs), r1cs["num_inputs"],
+                         r1cs["num_constraints"], z, z.shape[0], proof, inf, None)
+    assert rc == 0, rc
+    return proof, inf
