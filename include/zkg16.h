@@ -1,0 +1,149 @@
+/* zkg16 — MI355X-native Groth16 (BLS12-381) prove hot path, C ABI.
+ *
+ * Drop-in boundary for the inside of `Groth16::<Bls12_381>::prove(&pk, circuit, &mut rng)` as called by
+ * ArielElb/zkSnark-FinalProject:
+ *     src/arkworks/backend/matrix_proof.rs:139-140      (matrix-mul + Poseidon circuit)
+ *     src/arkworks/backend/fibbonaci_handler.rs:110     (Fibonacci circuit)
+ *     src/arkworks/backend/prime_snark.rs:119           (Fermat-prime circuit)
+ * The reference has no FFI layer of its own; the narrowest upstream seam is
+ *     ark_groth16::Groth16::create_proof_with_reduction_and_matrices(pk, r, s, &matrices, num_inputs,
+ *                                                                    num_constraints, &full_assignment)
+ * (ark-groth16 0.4 src/prover.rs, reached from the call sites above).  `zkg16_prove` is that function; the
+ * reference-side binding (Rust `extern "C"` + a `GpuGroth16::prove` wrapper) is shown in INTEGRATION.md.
+ *
+ * Data conventions (identical to arkworks' in-memory representation, so a Rust caller passes slices as-is):
+ *   Fr  = 4 little-endian u64 limbs, Montgomery form (R = 2^256)            (ark_bls12_381::Fr)
+ *   Fq  = 6 little-endian u64 limbs, Montgomery form (R = 2^384)            (ark_bls12_381::Fq)
+ *   G1 affine = 12 u64: x | y                                                (G1Affine.x, .y)
+ *   G2 affine = 24 u64: x.c0 | x.c1 | y.c0 | y.c1                             (G2Affine over Fq2)
+ *   point at infinity: separate flag byte per point (G?Affine.infinity); coordinates then ignored
+ *   "canonical" scalars = 4 LE u64 limbs of the plain residue (what `into_bigint()` yields)
+ * All inputs are caller-owned and copied before the call returns; outputs are caller-allocated.
+ * Every entry point returns a zkg16_status; nothing aborts or unwinds across this boundary.
+ * A ctx is bound to ONE GPU (one process per GPU; multi-GPU = one ctx per rank + zkg16_prove_partial /
+ * zkg16_prove_finish around a single all-gather of 5 partial points).
+ * Calls on one ctx are serialised by an internal mutex (actix workers may call concurrently:
+ * src/main.rs:37-43); pk / r1cs / witness handles are immutable after load.
+ */
+#ifndef ZKG16_H
+#define ZKG16_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define ZKG16_API __attribute__((visibility("default")))
+
+typedef enum {
+    ZKG16_OK = 0,
+    ZKG16_ERR_BAD_ARG = 1,          /* null pointer, inconsistent lengths */
+    ZKG16_ERR_DOMAIN_TOO_LARGE = 2, /* = ark SynthesisError::PolynomialDegreeTooLarge (domain > 2^32), or > build limit */
+    ZKG16_ERR_HIP = 3,              /* a HIP runtime call failed; see zkg16_last_error */
+    ZKG16_ERR_OOM = 4,
+    ZKG16_ERR_NO_DEVICE = 5,        /* no gfx950 device visible: the product has NO CPU fallback */
+    ZKG16_ERR_BAD_HANDLE = 6,
+    ZKG16_ERR_UNSUPPORTED = 7
+} zkg16_status;
+
+typedef struct zkg16_ctx zkg16_ctx;
+
+/* ---- lifecycle.  device_ids/n_devices: exactly one device per ctx (n_devices == 1). */
+ZKG16_API int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out);
+ZKG16_API void zkg16_destroy(zkg16_ctx *ctx);
+ZKG16_API const char *zkg16_strerror(int status);
+ZKG16_API const char *zkg16_last_error(zkg16_ctx *ctx); /* text of the last HIP failure on this ctx */
+ZKG16_API const char *zkg16_version(void);
+
+/* ---- proving key residency  (replaces holding `ProvingKey<Bls12_381>` on the host: matrix_proof.rs:129-140).
+ * Query lengths follow ark-groth16: n_a == n_b1 == n_b2 == num_instance + num_witness, n_h == N - 1,
+ * n_l == num_witness.  *_inf may be NULL (= no infinity points).  shard_index/shard_count: this ctx keeps
+ * only the contiguous index range [i*n/count, (i+1)*n/count) of every query vector (1 GPU: 0, 1). */
+ZKG16_API int zkg16_pk_load(zkg16_ctx *ctx,
+                  const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
+                  const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
+                  const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
+                  const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
+                  const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
+                  const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                  const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                  size_t num_instance, int shard_index, int shard_count, uint64_t *pk_handle);
+ZKG16_API void zkg16_pk_free(zkg16_ctx *ctx, uint64_t pk_handle);
+
+/* ---- R1CS residency (ark_relations `ConstraintMatrices<Fr>` as CSR; matrices are per-circuit constants).
+ * row_ptr: num_constraints + 1 entries; col: nnz u32; coeff: nnz x 4 limbs (Montgomery). */
+ZKG16_API int zkg16_r1cs_load(zkg16_ctx *ctx,
+                    const uint64_t *a_row_ptr, const uint32_t *a_col, const uint64_t *a_coeff,
+                    const uint64_t *b_row_ptr, const uint32_t *b_col, const uint64_t *b_coeff,
+                    const uint64_t *c_row_ptr, const uint32_t *c_col, const uint64_t *c_coeff,
+                    size_t num_instance, size_t num_constraints, size_t num_variables, uint64_t *r1cs_handle);
+ZKG16_API void zkg16_r1cs_free(zkg16_ctx *ctx, uint64_t r1cs_handle);
+
+/* ---- full assignment z = instance || witness (Montgomery), n_assign x 4 limbs, uploaded once per proof. */
+ZKG16_API int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n_assign, uint64_t *witness_handle);
+ZKG16_API void zkg16_witness_free(zkg16_ctx *ctx, uint64_t witness_handle);
+
+/* ---- the hot path.  r, s: Montgomery Fr (drawn by the caller exactly as ark-groth16 does: r then s).
+ * proof_out = A (12) | B (24) | C (12) affine Montgomery limbs; inf_out[3] = infinity flags of A, B, C. */
+ZKG16_API int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
+                         const uint64_t r[4], const uint64_t s[4], uint64_t proof_out[48], uint8_t inf_out[3]);
+
+/* One-shot form mirroring create_proof_with_reduction_and_matrices: host pointers in, proof out
+ * (uploads matrices + assignment, proves, frees). */
+ZKG16_API int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
+                const uint64_t *a_row_ptr, const uint32_t *a_col, const uint64_t *a_coeff,
+                const uint64_t *b_row_ptr, const uint32_t *b_col, const uint64_t *b_coeff,
+                const uint64_t *c_row_ptr, const uint32_t *c_col, const uint64_t *c_coeff,
+                size_t num_instance, size_t num_constraints,
+                const uint64_t *full_assignment, size_t n_assign,
+                uint64_t proof_out[48], uint8_t inf_out[3]);
+
+/* Multi-GPU (index-range sharded pk): each rank computes h redundantly and the MSM partial sums over its shard.
+ * partial_out = 4 G1 affine (H, L, A, B1 partials: 4 x 12) | 1 G2 affine (B2 partial: 24) = 72 u64;
+ * partial_inf[5].  The caller all-gathers the 72-u64 records (RCCL) and any rank finishes. */
+ZKG16_API int zkg16_prove_partial(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
+                        const uint64_t r[4], const uint64_t s[4], uint64_t partial_out[72], uint8_t partial_inf[5]);
+ZKG16_API int zkg16_prove_finish(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
+                       const uint64_t *partials /* n_ranks x 72 */, const uint8_t *partial_inf /* n_ranks x 5 */,
+                       int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]);
+
+/* ---- stage entry points (tests / bench; host buffers) ----------------------------------------- */
+/* ark-poly Radix2EvaluationDomain<Fr>: in-place, natural order; inverse => ifft (incl. 1/N);
+ * coset => offset g = 7 (coset_fft = g^i then fft; coset_ifft = ifft then g^-i). */
+ZKG16_API int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int coset);
+/* ark-ec VariableBaseMSM::msm_bigint: sum scalars[i] * bases[i]; result affine. */
+ZKG16_API int zkg16_msm_g1(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_canonical,
+                 size_t n, uint64_t out_affine[12], uint8_t *out_inf);
+ZKG16_API int zkg16_msm_g2(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_canonical,
+                 size_t n, uint64_t out_affine[24], uint8_t *out_inf);
+/* LibsnarkReduction::witness_map_from_matrices: h (N x 4 limbs, Montgomery), N = 2^log_n. */
+ZKG16_API int zkg16_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, uint64_t *h_out, size_t *log_n_out);
+/* ark-ec FixedBase::msm: out[i] = [scalars[i]] base (used by the known-trapdoor setup in tests/bench). */
+ZKG16_API int zkg16_fixed_base_g1(zkg16_ctx *ctx, const uint64_t base[12], const uint64_t *scalars_canonical, size_t n,
+                        uint64_t *out_affine /* n x 12 */, uint8_t *out_inf /* n */);
+ZKG16_API int zkg16_fixed_base_g2(zkg16_ctx *ctx, const uint64_t base[24], const uint64_t *scalars_canonical, size_t n,
+                        uint64_t *out_affine /* n x 24 */, uint8_t *out_inf /* n */);
+
+/* ---- device-resident stage benches (inputs uploaded once, op repeated on device) ---------------- */
+ZKG16_API int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int iters, float *ms_per_iter);
+ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t *bases, const uint8_t *inf,
+                    const uint64_t *scalars_canonical, size_t n, int iters, float *ms_per_iter,
+                    uint64_t *out_affine, uint8_t *out_inf);
+
+/* ---- instrumentation --------------------------------------------------------------------------- */
+/* Per-stage device time of the last prove on this ctx (hipEvent pairs on the ctx stream), in ms:
+ * [0] spmv, [1] ntt+pointwise, [2] msm digits+sort, [3] msm H, [4] msm L, [5] msm A, [6] msm B1, [7] msm B2,
+ * [8] host tail, [9] total wall.  Returns the number of entries written. */
+ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
+/* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0/1.  stats are
+ * accumulated per kernel name since the last reset. */
+ZKG16_API int zkg16_kernel_timing(zkg16_ctx *ctx, int enable);
+ZKG16_API int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms,
+                       double *units /* kernel-specific work units, e.g. bucket additions */);
+ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
+/* Tuning knobs (0 = default): MSM window bits c. */
+ZKG16_API int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKG16_H */

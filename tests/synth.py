@@ -1,0 +1,74 @@
+"""Synthetic satisfiable R1CS instances + known-trapdoor proving keys for the parity tests and bench.
+(Test infrastructure: uses the oracle for the trapdoor logs.)"""
+import random
+
+import numpy as np
+
+import pyref as P
+from helpers import *
+
+
+def random_r1cs(rng, nc, num_inputs, num_vars, max_nnz=4):
+    """Satisfiable random R1CS (python ints). Same construction as tests/golden/gen_golden.py."""
+    z = [1] + [P.rand_fr(rng) for _ in range(num_vars - 1)]
+    if num_vars > 5:
+        z[4] = 0
+        z[5] = 1
+    A, B, C = [], [], []
+    for i in range(nc):
+        ra = [(P.rand_fr(rng) if rng.random() < .5 else rng.randrange(1, 4), rng.randrange(num_vars))
+              for _ in range(rng.randrange(1, max_nnz + 1))]
+        rb = [(P.rand_fr(rng) if rng.random() < .5 else 1, rng.randrange(num_vars))
+              for _ in range(rng.randrange(1, max_nnz + 1))]
+        if i % 7 == 3:
+            rb = []
+        av = sum(c * z[j] for c, j in ra) % P.R_MOD
+        bv = sum(c * z[j] for c, j in rb) % P.R_MOD
+        target = av * bv % P.R_MOD
+        j = rng.randrange(1, num_vars)
+        c1 = P.rand_fr(rng)
+        rc = [(c1, j), ((target - c1 * z[j]) % P.R_MOD, 0)]
+        if i % 7 == 3:
+            rc = []
+        A.append(ra)
+        B.append(rb)
+        C.append(rc)
+    return A, B, C, z
+
+
+def r1cs_arrays(A, B, C, num_inputs):
+    return dict(a=csr_from_rows(A), b=csr_from_rows(B), c=csr_from_rows(C), num_inputs=num_inputs, num_constraints=len(A))
+
+
+def make_pk(oracle, r1cs, num_vars, rng, point_gen=None):
+    """Known-trapdoor Groth16 proving key (ark-groth16 generator.rs semantics, random generators).
+    point_gen(group, base_limbs, scalars_canonical) -> (points, inf); defaults to the oracle's fixed-base."""
+    trap_int = {k: P.rand_fr(rng) for k in ("tau", "alpha", "beta", "gamma", "delta")}
+    g1s, g2s = P.rand_fr(rng), P.rand_fr(rng)
+    trap = fr_mont_vec([trap_int[k] for k in ("tau", "alpha", "beta", "gamma", "delta")])
+    logs = oracle.setup_logs(r1cs, num_vars, trap)
+    gen = point_gen or oracle.fixed_base
+    g1 = oracle.point_mul("g1", G1_GEN_LIMBS, fr_canon(g1s))[0]
+    g2 = oracle.point_mul("g2", G2_GEN_LIMBS, fr_canon(g2s))[0]
+    canon = {k: oracle.fr_to_canonical(logs[k]) for k in ("a", "b", "l", "h")}
+    pk = {}
+    pk["a_query"], pk["a_inf"] = gen("g1", g1, canon["a"])
+    pk["b_g1_query"], pk["b_g1_inf"] = gen("g1", g1, canon["b"])
+    pk["b_g2_query"], pk["b_g2_inf"] = gen("g2", g2, canon["b"])
+    pk["h_query"], pk["h_inf"] = gen("g1", g1, canon["h"]) if canon["h"].shape[0] else (np.zeros((0, 12), np.uint64), np.zeros(0, np.uint8))
+    pk["l_query"], pk["l_inf"] = gen("g1", g1, canon["l"])
+    single = fr_canon_vec([trap_int["alpha"], trap_int["beta"], trap_int["delta"]])
+    p1, _ = gen("g1", g1, single)
+    p2, _ = gen("g2", g2, single)
+    pk["alpha_g1"], pk["beta_g1"], pk["delta_g1"] = p1[0], p1[1], p1[2]
+    pk["beta_g2"], pk["delta_g2"] = p2[1], p2[2]
+    meta = dict(trap=trap_int, g1s=g1s, g2s=g2s, logs=logs, g1=g1, g2=g2)
+    return pk, meta
+
+
+def expected_proof_logs(meta, logs_int, h_int, z_int, num_inputs, r, s):
+    """(a, b, c) discrete logs w.r.t. (g1, g2) + the Groth16 equation in the exponent."""
+    t = meta["trap"]
+    L = dict(a_query=logs_int["a"], b_query=logs_int["b"], l_query=logs_int["l"], h_query=logs_int["h"],
+             gamma_abc=logs_int["gabc"], alpha=t["alpha"], beta=t["beta"], gamma=t["gamma"], delta=t["delta"])
+    return P.groth16_prove_logs(L, h_int, z_int, num_inputs, r, s)

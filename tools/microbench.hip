@@ -1,0 +1,156 @@
+// Instruction-throughput microbenchmark for the integer paths a 381-bit Montgomery product can be built from
+// on gfx950.  Prints ops/s per instruction kind at full-chip occupancy.  (Development tool, not product.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include "../zksnark-finalproject_amd/csrc/ff.cuh"
+using namespace zk;
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+constexpr int ITERS = 4096;
+
+#define DEF_KERNEL(name, decl, body)                                          \
+    __global__ void __launch_bounds__(256) name(uint32_t *out, uint32_t seed) { \
+        decl;                                                                 \
+        for (int it = 0; it < ITERS; it++) { body; }                          \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = sink;                    \
+    }
+
+// 8 independent accumulators per lane to cover the pipeline latency
+__global__ void __launch_bounds__(256) k_mad_u64_u32(uint32_t *out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    uint32_t x = seed * 2654435761u + threadIdx.x, y = x ^ 0x9e3779b9u;
+    for (int it = 0; it < ITERS; it++) {
+#define M(a) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y) : "vcc");
+        M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+#define K32(name, INS)                                                                                          \
+    __global__ void __launch_bounds__(256) name(uint32_t *out, uint32_t seed) {                                 \
+        uint32_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t x = seed * 2654435761u + threadIdx.x;                                                          \
+        for (int it = 0; it < ITERS; it++) {                                                                    \
+            asm volatile(INS : "+v"(a0) : "v"(x)); asm volatile(INS : "+v"(a1) : "v"(x));                       \
+            asm volatile(INS : "+v"(a2) : "v"(x)); asm volatile(INS : "+v"(a3) : "v"(x));                       \
+            asm volatile(INS : "+v"(a4) : "v"(x)); asm volatile(INS : "+v"(a5) : "v"(x));                       \
+            asm volatile(INS : "+v"(a6) : "v"(x)); asm volatile(INS : "+v"(a7) : "v"(x));                       \
+        }                                                                                                       \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                      \
+    }
+K32(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
+K32(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
+K32(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %0")
+K32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+K32(k_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %1")
+K32(k_add_u32, "v_add_u32 %0, %0, %1")
+K32(k_add3_u32, "v_add3_u32 %0, %0, %1, %0")
+K32(k_mov_b32, "v_mov_b32 %0, %1")
+K32(k_mad_u32_u16, "v_mad_u32_u16 %0, %0, %1, %0")
+K32(k_addc, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+
+__global__ void __launch_bounds__(256) k_lshl_add_u64(uint32_t *out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    uint64_t x = seed * 2654435761u + threadIdx.x;
+    for (int it = 0; it < ITERS; it++) {
+#define M(a) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a) : "v"(x));
+        M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void __launch_bounds__(256) k_fma_f64(uint32_t *out, uint32_t seed) {
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double x = 1.0000001, y = 1e-9;
+    for (int it = 0; it < ITERS; it++) {
+#define M(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+        M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+__global__ void __launch_bounds__(256) k_fma_f32(uint32_t *out, uint32_t seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float x = 1.0000001f, y = 1e-9f;
+    for (int it = 0; it < ITERS; it++) {
+#define M(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));
+        M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+// the product's own Fq / Fr Montgomery multiplication, dependent chain per lane (throughput comes from occupancy)
+__global__ void __launch_bounds__(256) k_fq_mul(uint32_t *out, uint32_t seed) {
+    Fq a = Fq::one(), b = Fq::r2();
+    a.l[0] += threadIdx.x; b.l[1] ^= seed;
+    for (int it = 0; it < ITERS / 16; it++) { a = fp_mul(a, b); b = fp_mul(b, a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
+}
+__global__ void __launch_bounds__(256) k_fq_mul_inline(uint32_t *out, uint32_t seed) {
+    Fq a = Fq::one(), b = Fq::r2();
+    a.l[0] += threadIdx.x; b.l[1] ^= seed;
+    for (int it = 0; it < ITERS / 16; it++) { a = fp_mul_inline(a, b); b = fp_mul_inline(b, a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
+}
+__global__ void __launch_bounds__(256) k_fr_mul(uint32_t *out, uint32_t seed) {
+    Fr a = Fr::one(), b = Fr::r2();
+    a.l[0] += threadIdx.x; b.l[1] ^= seed;
+    for (int it = 0; it < ITERS / 16; it++) { a = fp_mul(a, b); b = fp_mul(b, a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
+}
+
+template <class K>
+static int run(const char *name, K kernel, double ops_per_thread, int blocks_per_cu, uint32_t *d_out) {
+    const int cus = 256, threads = 256;
+    const int grid = cus * blocks_per_cu;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, 0, d_out, 12345u);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    const int reps = 5;
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, 0, d_out, 12345u + i);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double total_ops = ops_per_thread * (double)grid * threads * reps;
+    const double rate = total_ops / (ms * 1e-3);
+    // cycles per wave-instruction per SIMD at 2.4 GHz: 1024 SIMDs
+    const double wave_instr_per_s = rate / 64.0;
+    const double cyc = 2.4e9 * 1024.0 / wave_instr_per_s;
+    printf("%-22s blocks/CU=%d  %8.3f ms  %10.3f Gop/s   ~%6.2f cyc/wave-instr/SIMD @2.4GHz\n", name, blocks_per_cu, ms / reps, rate * 1e-9, cyc);
+    return 0;
+}
+
+int main() {
+    uint32_t *d_out;
+    CHK(hipMalloc(&d_out, 256 * 8 * 256 * sizeof(uint32_t)));
+    const double per = 8.0 * ITERS;
+    for (int b : {4, 8}) {
+        run("v_mad_u64_u32", k_mad_u64_u32, per, b, d_out);
+        run("v_mul_lo_u32", k_mul_lo_u32, per, b, d_out);
+        run("v_mul_hi_u32", k_mul_hi_u32, per, b, d_out);
+        run("v_mad_u32_u24", k_mad_u32_u24, per, b, d_out);
+        run("v_mul_u32_u24", k_mul_u32_u24, per, b, d_out);
+        run("v_mul_hi_u32_u24", k_mul_hi_u32_u24, per, b, d_out);
+        run("v_mad_u32_u16", k_mad_u32_u16, per, b, d_out);
+        run("v_add_u32", k_add_u32, per, b, d_out);
+        run("v_add3_u32", k_add3_u32, per, b, d_out);
+        run("v_addc_co_u32", k_addc, per, b, d_out);
+        run("v_mov_b32", k_mov_b32, per, b, d_out);
+        run("v_lshl_add_u64", k_lshl_add_u64, per, b, d_out);
+        run("v_fma_f32", k_fma_f32, per, b, d_out);
+        run("v_fma_f64", k_fma_f64, per, b, d_out);
+    }
+    const double muls = 2.0 * (ITERS / 16);
+    for (int b : {1, 2, 4, 8}) {
+        run("Fq mul (call)", k_fq_mul, muls, b, d_out);
+        run("Fq mul (inline)", k_fq_mul_inline, muls, b, d_out);
+        run("Fr mul (inline)", k_fr_mul, muls, b, d_out);
+    }
+    hipFree(d_out);
+    return 0;
+}

@@ -1,0 +1,680 @@
+// libzkg16 C ABI (include/zkg16.h): context, proving-key / R1CS / witness residency, the prove pipeline and
+// its O(1) host tail.  Mirrors ark-groth16 0.4 `create_proof_with_reduction_and_matrices` +
+// `create_proof_with_assignment` (src/prover.rs) as reached from
+// /root/reference/src/arkworks/backend/matrix_proof.rs:139-140.
+//
+// There is NO CPU fallback: without a HIP device zkg16_init fails with ZKG16_ERR_NO_DEVICE.
+#include <chrono>
+
+#include "common.hpp"
+
+using namespace zk;
+
+namespace {
+
+const char *k_version = "zkg16 0.1 (gfx950; BLS12-381 Groth16 prove hot path)";
+
+int fail(zkg16_ctx *ctx, const HipError &e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.err), e.file, e.line);
+    if (ctx) ctx->last_error = buf;
+    (void)hipGetLastError();
+    if (e.err == hipErrorOutOfMemory) return ZKG16_ERR_OOM;
+    if (e.err == hipErrorInvalidValue && strstr(e.what, "domain")) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    return ZKG16_ERR_HIP;
+}
+
+#define ZK_API_BEGIN(ctx)                         \
+    if (!(ctx)) return ZKG16_ERR_BAD_ARG;         \
+    std::lock_guard<std::mutex> _lk((ctx)->mu);   \
+    try {                                         \
+        ZK_HIP(hipSetDevice((ctx)->device));
+#define ZK_API_END(ctx)                           \
+    }                                             \
+    catch (const HipError &e) { return fail((ctx), e); } \
+    catch (const std::bad_alloc &) { return ZKG16_ERR_OOM; } \
+    return ZKG16_OK;
+
+template <class T>
+T *find_handle(std::map<uint64_t, std::unique_ptr<T>> &m, uint64_t h) {
+    auto it = m.find(h);
+    return it == m.end() ? nullptr : it->second.get();
+}
+
+// ---- host <-> ABI point conversions (u64 limbs and u32 limbs share the little-endian byte layout)
+G1Affine g1_from_abi(const uint64_t *l, int inf) {
+    G1Affine p;
+    if (inf) return G1Affine::inf();
+    memcpy(&p, l, sizeof p);
+    return p;
+}
+G2Affine g2_from_abi(const uint64_t *l, int inf) {
+    G2Affine p;
+    if (inf) return G2Affine::inf();
+    memcpy(&p, l, sizeof p);
+    return p;
+}
+template <class A>
+void point_to_abi(const A &p, uint64_t *out, uint8_t *inf) {
+    if (p.is_inf()) {
+        memset(out, 0, sizeof p);
+        if (inf) *inf = 1;
+    } else {
+        memcpy(out, &p, sizeof p);
+        if (inf) *inf = 0;
+    }
+}
+
+// Upload a slice [lo, hi) of an affine query vector into dst[0 .. hi-lo), zeroing flagged-infinity points.
+template <class A>
+void upload_points(zkg16_ctx *ctx, A *dst, const uint64_t *src, const uint8_t *inf, size_t lo, size_t hi) {
+    if (hi <= lo) return;
+    const size_t n = hi - lo;
+    const A *s = reinterpret_cast<const A *>(src) + lo;
+    if (!inf) {
+        ZK_HIP(hipMemcpyAsync(dst, s, n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    std::vector<A> tmp(s, s + n);
+    for (size_t i = 0; i < n; i++)
+        if (inf[lo + i]) tmp[i] = A::inf();
+    ZK_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+template <class A>
+void upload_one(zkg16_ctx *ctx, A *dst, const A &p) {
+    ZK_HIP(hipMemcpyAsync(dst, &p, sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+struct Partials {
+    G1XYZZ h, l, a, b1;
+    G2XYZZ b2;
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// The device part of a proof: witness map + the five MSMs over this ctx's pk shard.
+void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const Fr &r, const Fr &s, Partials &out) {
+    const size_t m_total = rc.num_variables;
+    if (wit.n != m_total || pk.m_total != m_total) throw HipError{hipErrorInvalidValue, "prove: assignment / key length mismatch", __FILE__, __LINE__};
+    const size_t N = (size_t)1 << rc.log_n;
+    if (pk.n_h_total != N - 1) throw HipError{hipErrorInvalidValue, "prove: h_query length != N-1", __FILE__, __LINE__};
+    hipEvent_t ev[8];
+    for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
+    const double t0 = now_ms();
+    ZK_HIP(hipEventRecord(ev[0], ctx->stream));
+
+    // ---- R1CS -> QAP: h (Montgomery), a3-a5 of SURVEY.md 8a
+    Fr *h = nullptr;
+    {
+        // SpMV is timed apart from the NTTs
+        const size_t n = N;
+        for (int i = 0; i < 4; i++) ctx->poly[i].ensure(n * sizeof(Fr));
+    }
+    witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
+    ZK_HIP(hipEventRecord(ev[1], ctx->stream));
+
+    // ---- scalar vectors in canonical form
+    const size_t nz = pk.z_hi - pk.z_lo;
+    const size_t nzs = nz + 3;                                 // + r, s, -rs slots
+    const size_t nh = pk.h_hi - pk.h_lo;
+    ctx->ws_z.scalars.ensure(nzs * sizeof(Fr));
+    ctx->ws_h.scalars.ensure((nh ? nh : 1) * sizeof(Fr));
+    Fr *zs = ctx->ws_z.scalars.as<Fr>();
+    Fr *hs = ctx->ws_h.scalars.as<Fr>();
+    {
+        Fr extra[3];
+        const bool first = pk.shard_index == 0;               // the r/s/-rs terms are added by shard 0 only
+        extra[0] = first ? r : Fr::zero();
+        extra[1] = first ? s : Fr::zero();
+        extra[2] = first ? fp_neg(fp_mul(r, s)) : Fr::zero();
+        // stage z-slice || extras (Montgomery) in poly[1] (free after the witness map), then convert
+        Fr *stage = ctx->poly[1].as<Fr>();
+        ctx->poly[1].ensure(nzs * sizeof(Fr));
+        stage = ctx->poly[1].as<Fr>();
+        if (nz) ZK_HIP(hipMemcpyAsync(stage, wit.z.as<Fr>() + pk.z_lo, nz * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(stage + nz, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));            // `extra` is a stack buffer
+        fr_from_mont_run(ctx, stage, zs, nzs);
+        if (nh) fr_from_mont_run(ctx, h + pk.h_lo, hs, nh);
+    }
+    MsmPlan plan_z, plan_h;
+    msm_plan_build(ctx, ctx->ws_z, zs, nzs, plan_z);
+    msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
+    ZK_HIP(hipEventRecord(ev[2], ctx->stream));
+
+    out.h = msm_g1_exec(ctx, ctx->ws_h, plan_h, pk.h.as<G1Affine>(), "H");
+    ZK_HIP(hipEventRecord(ev[3], ctx->stream));
+    out.l = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.l.as<G1Affine>(), "L");
+    ZK_HIP(hipEventRecord(ev[4], ctx->stream));
+    out.a = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.a.as<G1Affine>(), "A");
+    ZK_HIP(hipEventRecord(ev[5], ctx->stream));
+    out.b1 = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.b1.as<G1Affine>(), "B1");
+    ZK_HIP(hipEventRecord(ev[6], ctx->stream));
+    out.b2 = msm_g2_exec(ctx, ctx->ws_z, plan_z, pk.b2.as<G2Affine>(), "B2");
+    ZK_HIP(hipEventRecord(ev[7], ctx->stream));
+    ZK_HIP(hipEventSynchronize(ev[7]));
+    float ms;
+    // [0] spmv (reported inside [1] for now), [1] witness map, [2] digits+sort, [3..7] MSMs
+    ctx->timings[0] = 0;
+    for (int i = 1; i <= 7; i++) {
+        ZK_HIP(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
+        ctx->timings[i] = ms;
+    }
+    ctx->timings[9] = (float)(now_ms() - t0);
+    for (auto &e : ev) (void)hipEventDestroy(e);
+}
+
+// Host tail (a9): A = alpha + MSM_a, B = beta + MSM_b, C = s*A + r*B1 + MSM_l + MSM_h.
+// (r*delta, s*delta and -rs*delta already ride inside the MSMs as three extra (base, scalar) slots.)
+void prove_tail(PkDev &pk, const Fr &r, const Fr &s, const Partials &p, uint64_t *proof_out, uint8_t *inf_out) {
+    G1XYZZ A = p.a;
+    xyzz_madd(A, pk.alpha_g1, false);
+    G1XYZZ B1 = p.b1;
+    xyzz_madd(B1, pk.beta_g1, false);
+    G2XYZZ B2 = p.b2;
+    xyzz_madd(B2, pk.beta_g2, false);
+    const Fr rc = fp_from_mont(r), sc = fp_from_mont(s);
+    G1XYZZ C = xyzz_mul(A, sc.l);
+    G1XYZZ rB = xyzz_mul(B1, rc.l);
+    xyzz_add(C, rB);
+    xyzz_add(C, p.l);
+    xyzz_add(C, p.h);
+    point_to_abi(xyzz_to_affine(A), proof_out, inf_out);
+    point_to_abi(xyzz_to_affine(B2), proof_out + 12, inf_out + 1);
+    point_to_abi(xyzz_to_affine(C), proof_out + 36, inf_out + 2);
+}
+
+Fr fr_from_abi(const uint64_t *l) {
+    Fr v;
+    memcpy(&v, l, sizeof v);
+    return v;
+}
+
+int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3],
+              size_t num_instance, size_t num_constraints, size_t num_variables, uint64_t *handle) {
+    if (!handle || num_instance == 0) return ZKG16_ERR_BAD_ARG;
+    for (int i = 0; i < 3; i++)
+        if (!rp[i] || (rp[i][num_constraints] && (!col[i] || !cf[i]))) return ZKG16_ERR_BAD_ARG;
+    const size_t dom = num_constraints + num_instance;
+    int log_n = 0;
+    while (((size_t)1 << log_n) < dom) log_n++;
+    if (log_n > 32) return ZKG16_ERR_DOMAIN_TOO_LARGE;      // ark: SynthesisError::PolynomialDegreeTooLarge
+    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;      // build limit of the two-pass NTT
+    auto r = std::make_unique<R1csDev>();
+    r->num_instance = num_instance;
+    r->num_constraints = num_constraints;
+    r->num_variables = num_variables;
+    r->log_n = log_n;
+    for (int i = 0; i < 3; i++) {
+        const size_t nnz = rp[i][num_constraints];
+        for (size_t k = 0; k < nnz; k++)
+            if (col[i][k] >= num_variables) return ZKG16_ERR_BAD_ARG;
+        r->nnz[i] = nnz;
+        r->rp[i].alloc((num_constraints + 1) * sizeof(uint64_t));
+        r->col[i].alloc(nnz * sizeof(uint32_t));
+        r->cf[i].alloc(nnz * sizeof(Fr));
+        ZK_HIP(hipMemcpyAsync(r->rp[i].p, rp[i], (num_constraints + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        if (nnz) {
+            ZK_HIP(hipMemcpyAsync(r->col[i].p, col[i], nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            ZK_HIP(hipMemcpyAsync(r->cf[i].p, cf[i], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    *handle = ctx->next_handle++;
+    ctx->r1cs[*handle] = std::move(r);
+    return ZKG16_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *zkg16_version(void) { return k_version; }
+
+const char *zkg16_strerror(int status) {
+    switch (status) {
+        case ZKG16_OK: return "ok";
+        case ZKG16_ERR_BAD_ARG: return "bad argument";
+        case ZKG16_ERR_DOMAIN_TOO_LARGE: return "evaluation domain too large (ark: PolynomialDegreeTooLarge)";
+        case ZKG16_ERR_HIP: return "HIP runtime error";
+        case ZKG16_ERR_OOM: return "out of memory";
+        case ZKG16_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case ZKG16_ERR_BAD_HANDLE: return "unknown handle";
+        case ZKG16_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char *zkg16_last_error(zkg16_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
+    if (!out) return ZKG16_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n_devices != 1 && !(n_devices == 0 && !device_ids)) return ZKG16_ERR_UNSUPPORTED;   // one GPU per ctx / process
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return ZKG16_ERR_NO_DEVICE;
+    }
+    const int dev = (n_devices == 1 && device_ids) ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return ZKG16_ERR_BAD_ARG;
+    auto *ctx = new (std::nothrow) zkg16_ctx();
+    if (!ctx) return ZKG16_ERR_OOM;
+    ctx->device = dev;
+    try {
+        ZK_HIP(hipSetDevice(dev));
+        hipDeviceProp_t prop;
+        ZK_HIP(hipGetDeviceProperties(&prop, dev));
+        ctx->num_cus = prop.multiProcessorCount;
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    } catch (const HipError &e) {
+        int rc = fail(ctx, e);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return ZKG16_OK;
+}
+
+void zkg16_destroy(zkg16_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pks.clear();
+    ctx->r1cs.clear();
+    ctx->wits.clear();
+    ctx->ntt_tables.clear();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return ZKG16_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "window_bits")) {
+        if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_window_bits = (int)value;
+        return ZKG16_OK;
+    }
+    return ZKG16_ERR_UNSUPPORTED;
+}
+
+int zkg16_pk_load(zkg16_ctx *ctx,
+                  const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
+                  const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
+                  const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
+                  const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
+                  const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
+                  const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                  const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                  size_t num_instance, int shard_index, int shard_count, uint64_t *pk_handle) {
+    if (!pk_handle || !a_query || !b_g1_query || !b_g2_query || (!h_query && n_h) || (!l_query && n_l) || !alpha_g1 || !beta_g1 ||
+        !beta_g2 || !delta_g1 || !delta_g2)
+        return ZKG16_ERR_BAD_ARG;
+    if (n_a == 0 || n_a != n_b1 || n_a != n_b2 || num_instance == 0 || num_instance > n_a || n_l != n_a - num_instance) return ZKG16_ERR_BAD_ARG;
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    auto pk = std::make_unique<PkDev>();
+    pk->num_instance = num_instance;
+    pk->m_total = n_a;
+    pk->n_h_total = n_h;
+    pk->shard_index = shard_index;
+    pk->shard_count = shard_count;
+    pk->z_lo = n_a * (size_t)shard_index / shard_count;
+    pk->z_hi = n_a * (size_t)(shard_index + 1) / shard_count;
+    pk->h_lo = n_h * (size_t)shard_index / shard_count;
+    pk->h_hi = n_h * (size_t)(shard_index + 1) / shard_count;
+    const size_t nz = pk->z_hi - pk->z_lo, nh = pk->h_hi - pk->h_lo;
+    pk->a.alloc((nz + 3) * sizeof(G1Affine));
+    pk->b1.alloc((nz + 3) * sizeof(G1Affine));
+    pk->l.alloc((nz + 3) * sizeof(G1Affine));
+    pk->b2.alloc((nz + 3) * sizeof(G2Affine));
+    pk->h.alloc((nh ? nh : 1) * sizeof(G1Affine));
+    ZK_HIP(hipMemsetAsync(pk->a.p, 0, pk->a.bytes, ctx->stream));      // (0,0) = infinity everywhere by default
+    ZK_HIP(hipMemsetAsync(pk->b1.p, 0, pk->b1.bytes, ctx->stream));
+    ZK_HIP(hipMemsetAsync(pk->l.p, 0, pk->l.bytes, ctx->stream));
+    ZK_HIP(hipMemsetAsync(pk->b2.p, 0, pk->b2.bytes, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    upload_points(ctx, pk->a.as<G1Affine>(), a_query, a_inf, pk->z_lo, pk->z_hi);
+    upload_points(ctx, pk->b1.as<G1Affine>(), b_g1_query, b_g1_inf, pk->z_lo, pk->z_hi);
+    upload_points(ctx, pk->b2.as<G2Affine>(), b_g2_query, b_g2_inf, pk->z_lo, pk->z_hi);
+    upload_points(ctx, pk->h.as<G1Affine>(), h_query, h_inf, pk->h_lo, pk->h_hi);
+    // l_query[j] pairs with z[num_instance + j]: place it at the same index as its scalar in this shard's z slice
+    {
+        const size_t lo = pk->z_lo > num_instance ? pk->z_lo : num_instance, hi = pk->z_hi;
+        if (hi > lo)
+            upload_points(ctx, pk->l.as<G1Affine>() + (lo - pk->z_lo), l_query, l_inf, lo - num_instance, hi - num_instance);
+    }
+    pk->alpha_g1 = g1_from_abi(alpha_g1, 0);
+    pk->beta_g1 = g1_from_abi(beta_g1, 0);
+    pk->delta_g1 = g1_from_abi(delta_g1, 0);
+    pk->beta_g2 = g2_from_abi(beta_g2, 0);
+    pk->delta_g2 = g2_from_abi(delta_g2, 0);
+    // extra slots (scalars r, s, -rs):  a += r*delta1 ; b1 += s*delta1 ; b2 += s*delta2 ; l += (-rs)*delta1
+    upload_one(ctx, pk->a.as<G1Affine>() + nz + 0, pk->delta_g1);
+    upload_one(ctx, pk->b1.as<G1Affine>() + nz + 1, pk->delta_g1);
+    upload_one(ctx, pk->b2.as<G2Affine>() + nz + 1, pk->delta_g2);
+    upload_one(ctx, pk->l.as<G1Affine>() + nz + 2, pk->delta_g1);
+    *pk_handle = ctx->next_handle++;
+    ctx->pks[*pk_handle] = std::move(pk);
+    ZK_API_END(ctx)
+}
+
+void zkg16_pk_free(zkg16_ctx *ctx, uint64_t h) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    ctx->pks.erase(h);
+}
+
+int zkg16_r1cs_load(zkg16_ctx *ctx,
+                    const uint64_t *a_row_ptr, const uint32_t *a_col, const uint64_t *a_coeff,
+                    const uint64_t *b_row_ptr, const uint32_t *b_col, const uint64_t *b_coeff,
+                    const uint64_t *c_row_ptr, const uint32_t *c_col, const uint64_t *c_coeff,
+                    size_t num_instance, size_t num_constraints, size_t num_variables, uint64_t *r1cs_handle) {
+    ZK_API_BEGIN(ctx)
+    const uint64_t *rp[3] = {a_row_ptr, b_row_ptr, c_row_ptr};
+    const uint32_t *col[3] = {a_col, b_col, c_col};
+    const uint64_t *cf[3] = {a_coeff, b_coeff, c_coeff};
+    int rc = load_r1cs(ctx, rp, col, cf, num_instance, num_constraints, num_variables, r1cs_handle);
+    if (rc) return rc;
+    ZK_API_END(ctx)
+}
+
+void zkg16_r1cs_free(zkg16_ctx *ctx, uint64_t h) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    ctx->r1cs.erase(h);
+}
+
+int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n_assign, uint64_t *witness_handle) {
+    if (!full_assignment || !witness_handle || n_assign == 0) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    auto w = std::make_unique<WitnessDev>();
+    w->n = n_assign;
+    w->z.alloc(n_assign * sizeof(Fr));
+    ZK_HIP(hipMemcpyAsync(w->z.p, full_assignment, n_assign * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    *witness_handle = ctx->next_handle++;
+    ctx->wits[*witness_handle] = std::move(w);
+    ZK_API_END(ctx)
+}
+
+void zkg16_witness_free(zkg16_ctx *ctx, uint64_t h) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    ctx->wits.erase(h);
+}
+
+int zkg16_prove_partial(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
+                        const uint64_t r[4], const uint64_t s[4], uint64_t partial_out[72], uint8_t partial_inf[5]) {
+    if (!r || !s || !partial_out || !partial_inf) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    if (!pk || !rc || !wit) return ZKG16_ERR_BAD_HANDLE;
+    if (wit->n != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != rc->num_instance ||
+        pk->n_h_total != ((size_t)1 << rc->log_n) - 1)
+        return ZKG16_ERR_BAD_ARG;
+    Partials p;
+    prove_device(ctx, *pk, *rc, *wit, fr_from_abi(r), fr_from_abi(s), p);
+    point_to_abi(xyzz_to_affine(p.h), partial_out, partial_inf);
+    point_to_abi(xyzz_to_affine(p.l), partial_out + 12, partial_inf + 1);
+    point_to_abi(xyzz_to_affine(p.a), partial_out + 24, partial_inf + 2);
+    point_to_abi(xyzz_to_affine(p.b1), partial_out + 36, partial_inf + 3);
+    point_to_abi(xyzz_to_affine(p.b2), partial_out + 48, partial_inf + 4);
+    ZK_API_END(ctx)
+}
+
+int zkg16_prove_finish(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
+                       const uint64_t *partials, const uint8_t *partial_inf, int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]) {
+    if (!r || !s || !partials || !partial_inf || n_ranks < 1 || !proof_out || !inf_out) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    if (!pk) return ZKG16_ERR_BAD_HANDLE;
+    Partials p;
+    p.h = p.l = p.a = p.b1 = G1XYZZ::inf();
+    p.b2 = G2XYZZ::inf();
+    for (int k = 0; k < n_ranks; k++) {
+        const uint64_t *q = partials + 72 * (size_t)k;
+        const uint8_t *f = partial_inf + 5 * (size_t)k;
+        xyzz_madd(p.h, g1_from_abi(q, f[0]), false);
+        xyzz_madd(p.l, g1_from_abi(q + 12, f[1]), false);
+        xyzz_madd(p.a, g1_from_abi(q + 24, f[2]), false);
+        xyzz_madd(p.b1, g1_from_abi(q + 36, f[3]), false);
+        xyzz_madd(p.b2, g2_from_abi(q + 48, f[4]), false);
+    }
+    prove_tail(*pk, fr_from_abi(r), fr_from_abi(s), p, proof_out, inf_out);
+    ZK_API_END(ctx)
+}
+
+int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
+                         const uint64_t r[4], const uint64_t s[4], uint64_t proof_out[48], uint8_t inf_out[3]) {
+    if (!r || !s || !proof_out || !inf_out) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    if (!pk || !rc || !wit) return ZKG16_ERR_BAD_HANDLE;
+    if (pk->shard_count != 1) return ZKG16_ERR_BAD_ARG;                 // sharded keys go through prove_partial/finish
+    if (wit->n != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != rc->num_instance ||
+        pk->n_h_total != ((size_t)1 << rc->log_n) - 1)
+        return ZKG16_ERR_BAD_ARG;
+    Partials p;
+    const Fr rr = fr_from_abi(r), ss = fr_from_abi(s);
+    prove_device(ctx, *pk, *rc, *wit, rr, ss, p);
+    const double t0 = now_ms();
+    prove_tail(*pk, rr, ss, p, proof_out, inf_out);
+    ctx->timings[8] = (float)(now_ms() - t0);
+    ctx->timings[9] += ctx->timings[8];
+    ZK_API_END(ctx)
+}
+
+int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
+                const uint64_t *a_row_ptr, const uint32_t *a_col, const uint64_t *a_coeff,
+                const uint64_t *b_row_ptr, const uint32_t *b_col, const uint64_t *b_coeff,
+                const uint64_t *c_row_ptr, const uint32_t *c_col, const uint64_t *c_coeff,
+                size_t num_instance, size_t num_constraints, const uint64_t *full_assignment, size_t n_assign,
+                uint64_t proof_out[48], uint8_t inf_out[3]) {
+    uint64_t rh = 0, wh = 0;
+    int rc = zkg16_r1cs_load(ctx, a_row_ptr, a_col, a_coeff, b_row_ptr, b_col, b_coeff, c_row_ptr, c_col, c_coeff, num_instance,
+                             num_constraints, n_assign, &rh);
+    if (rc) return rc;
+    rc = zkg16_witness_load(ctx, full_assignment, n_assign, &wh);
+    if (!rc) rc = zkg16_prove_resident(ctx, pk_handle, rh, wh, r, s, proof_out, inf_out);
+    if (wh) zkg16_witness_free(ctx, wh);
+    zkg16_r1cs_free(ctx, rh);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ stages
+int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int coset) {
+    if (!data) return ZKG16_ERR_BAD_ARG;
+    if (log_n > 32) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    ZK_API_BEGIN(ctx)
+    const size_t n = (size_t)1 << log_n;
+    DevBuf d(n * sizeof(Fr)), t(n * sizeof(Fr));
+    ZK_HIP(hipMemcpyAsync(d.p, data, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    ZK_HIP(hipMemcpyAsync(data, d.p, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_API_END(ctx)
+}
+
+int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int iters, float *ms_per_iter) {
+    if (!ms_per_iter || iters < 1) return ZKG16_ERR_BAD_ARG;
+    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    ZK_API_BEGIN(ctx)
+    const size_t n = (size_t)1 << log_n;
+    DevBuf d(n * sizeof(Fr)), t(n * sizeof(Fr));
+    ZK_HIP(hipMemsetAsync(d.p, 0x5a, n * sizeof(Fr), ctx->stream));       // arbitrary (unreduced) limbs: timing only
+    (void)ntt_get_tables(ctx, (int)log_n);
+    ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0));
+    ZK_HIP(hipEventCreate(&e1));
+    ZK_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; i++) ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    ZK_HIP(hipEventRecord(e1, ctx->stream));
+    ZK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_iter = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ZK_API_END(ctx)
+}
+
+}  // extern "C"
+
+namespace {
+
+template <class A, class X>
+int msm_host_entry(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, int iters,
+                   float *ms_per_iter, uint64_t *out_affine, uint8_t *out_inf, bool g2) {
+    if ((!bases || !scalars) && n) return ZKG16_ERR_BAD_ARG;
+    if (!out_affine) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    DevBuf d_bases((n ? n : 1) * sizeof(A)), d_sc((n ? n : 1) * sizeof(Fr));
+    if (n) {
+        upload_points(ctx, d_bases.as<A>(), bases, inf, 0, n);
+        ZK_HIP(hipMemcpyAsync(d_sc.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    X total = X::inf();
+    double ms_sum = 0;
+    for (int it = 0; it < (iters < 1 ? 1 : iters); it++) {
+        const double t0 = now_ms();
+        MsmPlan plan;
+        msm_plan_build(ctx, ctx->ws_h, d_sc.as<Fr>(), n, plan);
+        if constexpr (sizeof(A) == sizeof(G1Affine)) total = msm_g1_exec(ctx, ctx->ws_h, plan, d_bases.as<G1Affine>(), "msm");
+        else total = msm_g2_exec(ctx, ctx->ws_h, plan, d_bases.as<G2Affine>(), "msm");
+        ms_sum += now_ms() - t0;
+    }
+    if (ms_per_iter) *ms_per_iter = (float)(ms_sum / (iters < 1 ? 1 : iters));
+    point_to_abi(xyzz_to_affine(total), out_affine, out_inf);
+    (void)g2;
+    ZK_API_END(ctx)
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkg16_msm_g1(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_canonical, size_t n,
+                 uint64_t out_affine[12], uint8_t *out_inf) {
+    return msm_host_entry<G1Affine, G1XYZZ>(ctx, bases, inf, scalars_canonical, n, 1, nullptr, out_affine, out_inf, false);
+}
+int zkg16_msm_g2(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_canonical, size_t n,
+                 uint64_t out_affine[24], uint8_t *out_inf) {
+    return msm_host_entry<G2Affine, G2XYZZ>(ctx, bases, inf, scalars_canonical, n, 1, nullptr, out_affine, out_inf, true);
+}
+int zkg16_bench_msm(zkg16_ctx *ctx, int group, const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_canonical,
+                    size_t n, int iters, float *ms_per_iter, uint64_t *out_affine, uint8_t *out_inf) {
+    if (group == 1) return msm_host_entry<G1Affine, G1XYZZ>(ctx, bases, inf, scalars_canonical, n, iters, ms_per_iter, out_affine, out_inf, false);
+    if (group == 2) return msm_host_entry<G2Affine, G2XYZZ>(ctx, bases, inf, scalars_canonical, n, iters, ms_per_iter, out_affine, out_inf, true);
+    return ZKG16_ERR_BAD_ARG;
+}
+
+int zkg16_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, uint64_t *h_out, size_t *log_n_out) {
+    if (!h_out) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    if (!rc || !wit) return ZKG16_ERR_BAD_HANDLE;
+    if (wit->n != rc->num_variables) return ZKG16_ERR_BAD_ARG;
+    Fr *h = nullptr;
+    witness_map_run(ctx, *rc, wit->z.as<Fr>(), &h);
+    const size_t n = (size_t)1 << rc->log_n;
+    ZK_HIP(hipMemcpyAsync(h_out, h, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (log_n_out) *log_n_out = (size_t)rc->log_n;
+    ZK_API_END(ctx)
+}
+
+int zkg16_fixed_base_g1(zkg16_ctx *ctx, const uint64_t base[12], const uint64_t *scalars_canonical, size_t n, uint64_t *out_affine,
+                        uint8_t *out_inf) {
+    if (!base || (!scalars_canonical && n) || (!out_affine && n)) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    if (n) {
+        DevBuf d_sc(n * sizeof(Fr)), d_out(n * sizeof(G1Affine));
+        ZK_HIP(hipMemcpyAsync(d_sc.p, scalars_canonical, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        fixed_base_g1_run(ctx, g1_from_abi(base, 0), d_sc.as<Fr>(), n, d_out.as<G1Affine>());
+        ZK_HIP(hipMemcpyAsync(out_affine, d_out.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (out_inf) {
+            const G1Affine *o = reinterpret_cast<const G1Affine *>(out_affine);
+            for (size_t i = 0; i < n; i++) out_inf[i] = o[i].is_inf() ? 1 : 0;
+        }
+    }
+    ZK_API_END(ctx)
+}
+
+int zkg16_fixed_base_g2(zkg16_ctx *ctx, const uint64_t base[24], const uint64_t *scalars_canonical, size_t n, uint64_t *out_affine,
+                        uint8_t *out_inf) {
+    if (!base || (!scalars_canonical && n) || (!out_affine && n)) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    if (n) {
+        DevBuf d_sc(n * sizeof(Fr)), d_out(n * sizeof(G2Affine));
+        ZK_HIP(hipMemcpyAsync(d_sc.p, scalars_canonical, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        fixed_base_g2_run(ctx, g2_from_abi(base, 0), d_sc.as<Fr>(), n, d_out.as<G2Affine>());
+        ZK_HIP(hipMemcpyAsync(out_affine, d_out.p, n * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        if (out_inf) {
+            const G2Affine *o = reinterpret_cast<const G2Affine *>(out_affine);
+            for (size_t i = 0; i < n; i++) out_inf[i] = o[i].is_inf() ? 1 : 0;
+        }
+    }
+    ZK_API_END(ctx)
+}
+
+// ------------------------------------------------------------------------------------------------ instrumentation
+int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap) {
+    if (!ctx || !ms) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int n = cap < 10 ? cap : 10;
+    for (int i = 0; i < n; i++) ms[i] = ctx->timings[i];
+    return n;
+}
+
+int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {
+    if (!ctx) return ZKG16_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->kernel_timing = enable != 0;
+    return ZKG16_OK;
+}
+
+int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms, double *units) {
+    if (!ctx || !kernel_name) return ZKG16_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->kstats.find(kernel_name);
+    if (it == ctx->kstats.end()) {
+        if (launches) *launches = 0;
+        if (total_ms) *total_ms = 0;
+        if (units) *units = 0;
+        return ZKG16_OK;
+    }
+    if (launches) *launches = it->second.launches;
+    if (total_ms) *total_ms = it->second.ms;
+    if (units) *units = it->second.units;
+    return ZKG16_OK;
+}
+
+void zkg16_kernel_stats_reset(zkg16_ctx *ctx) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->kstats.clear();
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// Shared host-side plumbing for libzkg16: context, device buffers, error handling, kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zkg16.h"
+#include "ec.cuh"
+#include "ff.cuh"
+
+namespace zk {
+
+struct HipError {
+    hipError_t err;
+    const char *what;
+    const char *file;
+    int line;
+};
+
+#define ZK_HIP(expr)                                                 \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) throw zk::HipError{_e, #expr, __FILE__, __LINE__}; \
+    } while (0)
+
+// RAII device buffer (hipMalloc).  Throws HipError on failure (mapped to a status at the ABI edge).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        ZK_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void ensure(size_t n) { if (n > bytes) alloc(n); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg reads these).
+struct KernelStat { uint64_t launches = 0; double ms = 0, units = 0; };
+
+struct NttTables {          // per domain size, built on device on first use
+    int log_n = 0;
+    DevBuf w;               // w[j]  = omega_N^j,            j < N
+    DevBuf g;               // g[i]  = 7^i                   (coset fft pre-multiply)
+    DevBuf gi;              // gi[i] = 7^-i * N^-1           (coset ifft post-multiply)
+    Fr n_inv;               // N^-1 (plain ifft post-multiply)
+    Fr zinv;                // (7^N - 1)^-1 : 1 / Z on the coset (witness map)
+};
+
+struct PkDev {              // proving key shard resident in HBM (affine AoS; (0,0) = infinity)
+    size_t num_instance = 0, m_total = 0;            // m_total = num_instance + num_witness (full key)
+    size_t z_lo = 0, z_hi = 0;                       // index range of the a/b1/b2 (and padded l) queries kept here
+    size_t h_lo = 0, h_hi = 0, n_h_total = 0;        // index range of h_query kept here
+    DevBuf a, b1, l;                                 // G1Affine[z_hi - z_lo + 3]  (three trailing slots: r, s, -rs terms)
+    DevBuf b2;                                       // G2Affine[z_hi - z_lo + 3]
+    DevBuf h;                                        // G1Affine[h_hi - h_lo]
+    G1Affine a0, b1_0, alpha_g1, beta_g1, delta_g1;  // host copies for the tail
+    G2Affine b2_0, beta_g2, delta_g2;
+    int shard_index = 0, shard_count = 1;
+};
+
+struct R1csDev {
+    size_t num_instance = 0, num_constraints = 0, num_variables = 0;
+    int log_n = 0;
+    DevBuf rp[3], col[3], cf[3];
+    size_t nnz[3] = {0, 0, 0};
+};
+
+struct WitnessDev { size_t n = 0; DevBuf z; };
+
+struct MsmWorkspace {       // grown on demand, reused across proofs
+    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars;
+};
+
+}  // namespace zk
+
+struct zkg16_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string last_error;
+    std::map<int, std::unique_ptr<zk::NttTables>> ntt_tables;
+    std::map<uint64_t, std::unique_ptr<zk::PkDev>> pks;
+    std::map<uint64_t, std::unique_ptr<zk::R1csDev>> r1cs;
+    std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
+    uint64_t next_handle = 1;
+    zk::MsmWorkspace ws_z, ws_h;                      // one workspace per scalar vector (z-side, h-side)
+    zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
+    zk::DevBuf hscal;                                 // canonical h
+    float timings[16] = {0};
+    bool kernel_timing = false;
+    std::map<std::string, zk::KernelStat> kstats;
+    std::vector<hipEvent_t> ev_pool;
+    int opt_window_bits = 0;
+    int num_cus = 256;
+};
+
+namespace zk {
+
+// Brackets one kernel launch with HIP events when ctx->kernel_timing is on.
+struct ScopedKernelTimer {
+    zkg16_ctx *ctx;
+    const char *name;
+    double units;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ScopedKernelTimer(zkg16_ctx *c, const char *n, double u) : ctx(c), name(n), units(u) {
+        if (!ctx->kernel_timing) return;
+        ZK_HIP(hipEventCreate(&e0));
+        ZK_HIP(hipEventCreate(&e1));
+        ZK_HIP(hipEventRecord(e0, ctx->stream));
+    }
+    ~ScopedKernelTimer() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        auto &s = ctx->kstats[name];
+        s.launches++;
+        s.ms += ms;
+        s.units += units;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+};
+
+// ---- entry points implemented per translation unit
+void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset);   // result left in `data`
+NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n);
+
+void spmv_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c);
+void pointwise_h_run(zkg16_ctx *ctx, Fr *ab_a, const Fr *b, const Fr *c, const Fr &zinv, size_t n);
+void fr_from_mont_run(zkg16_ctx *ctx, const Fr *in, Fr *out, size_t n);
+void witness_map_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr **h_out);
+
+// Scalar-vector side of Pippenger (shared by every MSM over the same scalars).
+struct MsmPlan {
+    size_t n = 0;            // scalars
+    int c = 0, nwin = 0;     // window bits, window count
+    size_t nb = 0;           // buckets per window = 2^(c-1)
+    size_t total_entries = 0, nseg = 0;
+    int seg_len = 0;
+};
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
+// Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
+G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1Affine *bases, const char *tag);
+G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2Affine *bases, const char *tag);
+
+void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out);
+void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out);
+
+}  // namespace zk

@@ -1,0 +1,158 @@
+// BLS12-381 G1 (over Fq) and G2 (over Fq2) group arithmetic, y^2 = x^3 + b, a = 0.
+//
+// Device representation for bucket sums is extended Jacobian "XYZZ" (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
+// the mixed addition bucket += affine costs 8M + 2S (EFD madd-2008-s) versus 7M + 4S for Jacobian, and
+// needs no inversion.  Infinity <=> ZZ == 0.  Affine points coming from the proving key use
+// (x, y) = (0, 0) for the point at infinity (not on either curve), set at pk-load time from the
+// caller's flag bytes (arkworks `Affine { x, y, infinity }`, see include/zkg16.h).
+//
+// The group element is what must match the reference (Proof{a, b, c} are affine, canonical); the
+// projective representation is free.
+#pragma once
+#include "ff.cuh"
+
+namespace zk {
+
+template <class F>
+struct Affine {
+    F x, y;
+    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZK_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
+};
+
+template <class F>
+struct XYZZ {
+    F x, y, zz, zzz;
+    ZK_HD bool is_inf() const { return zz.is_zero(); }
+    ZK_HD static XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
+    ZK_HD static XYZZ from_affine(const Affine<F> &p) {
+        if (p.is_inf()) return inf();
+        return XYZZ{p.x, p.y, F::one(), F::one()};
+    }
+};
+
+// 2 * (affine p), p != inf  (EFD mdbl-2008-s-1)
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
+    F U = f_dbl(p.y);
+    F V = f_sqr(U);
+    F W = f_mul(U, V);
+    F S = f_mul(p.x, V);
+    F X2 = f_sqr(p.x);
+    F M = f_add(f_dbl(X2), X2);
+    XYZZ<F> r;
+    r.x = f_sub(f_sqr(M), f_dbl(S));
+    r.y = f_sub(f_mul(M, f_sub(S, r.x)), f_mul(W, p.y));
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+
+// 2 * p (EFD dbl-2008-s-1)
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
+    if (p.is_inf()) return p;
+    F U = f_dbl(p.y);
+    F V = f_sqr(U);
+    F W = f_mul(U, V);
+    F S = f_mul(p.x, V);
+    F X2 = f_sqr(p.x);
+    F M = f_add(f_dbl(X2), X2);
+    XYZZ<F> r;
+    r.x = f_sub(f_sqr(M), f_dbl(S));
+    r.y = f_sub(f_mul(M, f_sub(S, r.x)), f_mul(W, p.y));
+    r.zz = f_mul(V, p.zz);
+    r.zzz = f_mul(W, p.zzz);
+    return r;
+}
+
+// acc += (neg ? -q : q), q affine (EFD madd-2008-s) with all exceptional cases.
+template <class F>
+ZK_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bool neg) {
+    if (q_in.is_inf()) return;
+    Affine<F> q = q_in;
+    if (neg) q.y = f_neg(q.y);
+    if (acc.is_inf()) {
+        acc = XYZZ<F>{q.x, q.y, F::one(), F::one()};
+        return;
+    }
+    F U2 = f_mul(q.x, acc.zz);
+    F S2 = f_mul(q.y, acc.zzz);
+    F Pp = f_sub(U2, acc.x);
+    F R = f_sub(S2, acc.y);
+    if (Pp.is_zero()) {
+        if (R.is_zero()) acc = xyzz_dbl_affine(q);
+        else acc = XYZZ<F>::inf();
+        return;
+    }
+    F PP = f_sqr(Pp);
+    F PPP = f_mul(Pp, PP);
+    F Q = f_mul(acc.x, PP);
+    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    acc.y = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(acc.y, PPP));
+    acc.x = X3;
+    acc.zz = f_mul(acc.zz, PP);
+    acc.zzz = f_mul(acc.zzz, PPP);
+}
+
+// acc += q (EFD add-2008-s) with all exceptional cases.
+template <class F>
+ZK_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
+    if (q.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = q;
+        return;
+    }
+    F U1 = f_mul(acc.x, q.zz);
+    F U2 = f_mul(q.x, acc.zz);
+    F S1 = f_mul(acc.y, q.zzz);
+    F S2 = f_mul(q.y, acc.zzz);
+    F Pp = f_sub(U2, U1);
+    F R = f_sub(S2, S1);
+    if (Pp.is_zero()) {
+        if (R.is_zero()) acc = xyzz_dbl(acc);
+        else acc = XYZZ<F>::inf();
+        return;
+    }
+    F PP = f_sqr(Pp);
+    F PPP = f_mul(Pp, PP);
+    F Q = f_mul(U1, PP);
+    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    acc.y = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(S1, PPP));
+    acc.x = X3;
+    acc.zz = f_mul(f_mul(acc.zz, q.zz), PP);
+    acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), PPP);
+}
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_neg(const XYZZ<F> &p) {
+    return XYZZ<F>{p.x, f_neg(p.y), p.zz, p.zzz};
+}
+
+// x = X/ZZ, y = Y/ZZZ.  One inversion: (ZZ*ZZZ)^-1.  Host tail only.
+template <class F>
+ZK_HD Affine<F> xyzz_to_affine(const XYZZ<F> &p) {
+    if (p.is_inf()) return Affine<F>::inf();
+    F inv = f_inv(f_mul(p.zz, p.zzz));
+    F zz_inv = f_mul(inv, p.zzz);
+    F zzz_inv = f_mul(inv, p.zz);
+    return Affine<F>{f_mul(p.x, zz_inv), f_mul(p.y, zzz_inv)};
+}
+
+// [k]p for a 256-bit little-endian scalar (8 x u32, canonical).  Host tail + tests.
+template <class F>
+ZK_HD XYZZ<F> xyzz_mul(const XYZZ<F> &p, const uint32_t k[8]) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = 255; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k[i / 32] >> (i % 32)) & 1) xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+using G1Affine = Affine<Fq>;
+using G2Affine = Affine<Fq2>;
+using G1XYZZ = XYZZ<Fq>;
+using G2XYZZ = XYZZ<Fq2>;
+
+}  // namespace zk

@@ -1,0 +1,417 @@
+// Pippenger multi-scalar multiplication on gfx950 for the five MSMs of a Groth16 proof
+// (ark-ec 0.4.2 `VariableBaseMSM::msm_bigint` as called by ark-groth16 prover.rs for h_query, l_query,
+// a_query, b_g1_query (G1) and b_g2_query (G2); reached from
+// /root/reference/src/arkworks/backend/matrix_proof.rs:139-140).  The result is a group element, so only its
+// value is pinned by the reference; the schedule below is MI355X-first:
+//
+//  scalar side (once per scalar vector, shared by every MSM over it — A, B1, B2 and L all use z):
+//    msm_digits   signed radix-2^c digits (c up to 16), one key per (window, scalar), bucket histogram
+//    msm_scan     exclusive prefix sum of the W * 2^(c-1) bucket sizes
+//    msm_scatter  counting-sort scatter of (index, sign) entries into bucket order
+//  base side (per MSM):
+//    msm_accumulate  one lane per fixed-length SEGMENT of the bucket-sorted entry list (not per bucket), so
+//                    every lane of every wave performs exactly the same number of XYZZ mixed additions no matter
+//                    how skewed the scalars are (the reference's witnesses are ~10% ones: SURVEY.md 8d);
+//                    buckets fully inside a segment are written once, the <=2 straddling partials per lane
+//                    go to a side list that msm_fixup folds in.
+//    msm_reduce_level  weighted bucket sum  sum_b (b+1) B_b  as a log_K-depth tree: every level combines K
+//                    adjacent blocks (S, T) -> (sum S, sum T + |block| * sum j*S_j) with running sums.
+//    host: Horner over the W window sums (W*c doublings) — O(1), done in the proof tail.
+//
+// Arithmetic: 381-bit Montgomery on v_mad_u64_u32 — integer-ALU bound, not HBM bound: one mixed add is ~10 Fq
+// products (~3k VALU ops) per 96-B base gathered.  No MFMA (no dense contraction); LDS is used by the scan.
+#include "common.hpp"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------------ vector ld/st
+template <class T>
+__device__ __forceinline__ T ldv(const T *p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiple");
+    T v;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 *d = reinterpret_cast<uint4 *>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = q[i];
+    return v;
+}
+template <class T>
+__device__ __forceinline__ void stv(T *p, const T &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------------ scalar side
+// keys[w*n + i] = 0 (digit 0) or 1 + ((|d|-1) << 1 | neg)
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars, size_t n, int c, int nwin, size_t nb,
+                                                         uint32_t *keys, uint32_t *counts) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[9];
+    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + 8 * i);
+    uint4 lo = q[0], hi = q[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w; s[8] = 0;
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    for (int w = 0; w < nwin; w++) {
+        const int bit = w * c;
+        uint32_t v = 0;
+        if (bit < 256) {
+            const int limb = bit >> 5, off = bit & 31;
+            uint64_t two = (uint64_t)s[limb] | ((uint64_t)s[limb + 1] << 32);
+            v = (uint32_t)(two >> off) & mask;
+        }
+        v += carry;
+        uint32_t key = 0;
+        carry = 0;
+        if (v > half) {                       // recenter: d = v - 2^c <= 0, carry into the next window
+            const uint32_t mag = (1u << c) - v;
+            carry = 1;
+            if (mag) key = 1u + (((mag - 1u) << 1) | 1u);
+        } else if (v != 0) {
+            key = 1u + ((v - 1u) << 1);
+        }
+        keys[(size_t)w * n + i] = key;
+        if (key) atomicAdd(&counts[(size_t)w * nb + ((key - 1u) >> 1)], 1u);
+    }
+}
+
+// exclusive scan of counts[0..total) -> offsets[0..total]; single workgroup, LDS tree over per-thread partials
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *counts, uint32_t *offsets, size_t total) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const size_t per = (total + 1023) / 1024;
+    const size_t lo = (size_t)tid * per, hi = lo + per < total ? lo + per : total;
+    uint32_t sum = 0;
+    for (size_t k = lo; k < hi; k++) sum += counts[k];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {       // Hillis-Steele inclusive scan
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (size_t k = lo; k < hi; k++) {
+        offsets[k] = run;
+        run += counts[k];
+    }
+    if (tid == 1023) offsets[total] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *keys, size_t n, int nwin, size_t nb,
+                                                          const uint32_t *offsets, uint32_t *cursors, uint32_t *entries) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * (size_t)nwin) return;
+    const uint32_t key = keys[idx];
+    if (!key) return;
+    const size_t w = idx / n, i = idx - w * n;
+    const size_t g = w * nb + ((key - 1u) >> 1);
+    const uint32_t pos = offsets[g] + atomicAdd(&cursors[g], 1u);
+    entries[pos] = ((uint32_t)i << 1) | ((key - 1u) & 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ base side
+template <class F>
+struct AccArgs {
+    const Affine<F> *bases;
+    const uint32_t *entries, *offsets;
+    XYZZ<F> *buckets, *seg_head, *seg_tail;
+    int32_t *seg_meta;          // [2*t] = bucket of head partial or -1, [2*t+1] = bucket of tail partial or -1
+    size_t total_entries, total_buckets, nseg;
+    int seg_len;
+};
+
+template <class F>
+__global__ void __launch_bounds__(64) msm_accumulate_kernel(AccArgs<F> a) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nseg) return;
+    const size_t start = t * (size_t)a.seg_len;
+    const size_t end = start + a.seg_len < a.total_entries ? start + a.seg_len : a.total_entries;
+    // bucket containing `start`: largest g with offsets[g] <= start (and offsets[g+1] > start)
+    size_t lo = 0, hi = a.total_buckets;          // invariant: offsets[lo] <= start < offsets[hi]
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= start) lo = mid; else hi = mid;
+    }
+    size_t g = lo;
+    uint32_t g_end = a.offsets[g + 1];
+    int32_t head_b = -1, tail_b = -1;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    auto flush = [&](size_t gb, uint32_t gb_end) {
+        const uint32_t gb_start = a.offsets[gb];
+        if (gb_start < start) {                   // began in an earlier segment
+            head_b = (int32_t)gb;
+            stv(a.seg_head + t, acc);
+        } else if (gb_end > end) {                // continues into the next segment
+            tail_b = (int32_t)gb;
+            stv(a.seg_tail + t, acc);
+        } else if (!acc.is_inf()) {
+            stv(a.buckets + gb, acc);             // complete (buckets[] is pre-zeroed = infinity)
+        }
+        acc = XYZZ<F>::inf();
+    };
+    for (size_t p = start; p < end; p++) {
+        while (p >= g_end) {
+            if (a.offsets[g] < g_end) flush(g, g_end);    // skip empty buckets
+            g++;
+            g_end = a.offsets[g + 1];
+        }
+        const uint32_t e = a.entries[p];
+        const Affine<F> b = ldv(a.bases + (e >> 1));
+        xyzz_madd(acc, b, (e & 1u) != 0);
+    }
+    if (end > start) flush(g, g_end);
+    a.seg_meta[2 * t] = head_b;
+    a.seg_meta[2 * t + 1] = tail_b;
+}
+
+// One lane per segment whose last bucket spills over: add the head partials of the following segments.
+template <class F>
+__global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nseg) return;
+    const int32_t g = a.seg_meta[2 * t + 1];
+    if (g < 0) return;
+    XYZZ<F> sum = ldv(a.seg_tail + t);
+    for (size_t u = t + 1; u < a.nseg && a.seg_meta[2 * u] == g; u++) {
+        const XYZZ<F> h = ldv(a.seg_head + u);
+        xyzz_add(sum, h);
+    }
+    stv(a.buckets + g, sum);
+}
+
+// A bucket that begins exactly at a segment start and spans it entirely is recorded as that segment's HEAD
+// only if it began earlier; if it begins at the segment start it is a TAIL (gb_start == start, gb_end > end).
+// Hence every spilled bucket has exactly one tail record followed by head records — what msm_fixup walks.
+
+template <class F>
+struct ReduceArgs {
+    const XYZZ<F> *s_in, *t_in;   // [nwin][m]   (level 1: both = buckets)
+    XYZZ<F> *s_out, *t_out;       // [nwin][m/K]
+    size_t m;                     // blocks per window at this level
+    int k;                        // blocks combined per output
+    int log_block;                // log2(original buckets per input block)
+    int first;                    // level 1: t_in == s_in, skip the T sum
+    int nwin;
+};
+
+template <class F>
+__global__ void __launch_bounds__(64) msm_reduce_level_kernel(ReduceArgs<F> a) {
+    const size_t mo = a.m / a.k;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= mo * (size_t)a.nwin) return;
+    const size_t w = id / mo, d = id - w * mo;
+    const size_t base = w * a.m + d * a.k;
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf(), tsum = XYZZ<F>::inf();
+    for (int j = a.k - 1; j >= 1; j--) {
+        const XYZZ<F> sj = ldv(a.s_in + base + j);
+        xyzz_add(run, sj);
+        xyzz_add(acc, run);                       // acc = sum_j j * S_j
+        if (!a.first) {
+            const XYZZ<F> tj = ldv(a.t_in + base + j);
+            xyzz_add(tsum, tj);
+        }
+    }
+    const XYZZ<F> s0 = ldv(a.s_in + base);
+    xyzz_add(run, s0);                            // run = sum_j S_j
+    if (a.first) {
+        xyzz_add(acc, run);                       // sum_j (j+1) P_j
+    } else {
+        const XYZZ<F> t0 = ldv(a.t_in + base);
+        xyzz_add(tsum, t0);
+        for (int q = 0; q < a.log_block; q++) acc = xyzz_dbl(acc);
+        xyzz_add(acc, tsum);
+    }
+    stv(a.s_out + w * mo + d, run);
+    stv(a.t_out + w * mo + d, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ fixed base
+template <class F>
+__global__ void __launch_bounds__(64) fixed_base_table_kernel(const XYZZ<F> *win_bases /*32*/, Affine<F> *table /*32*255*/) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 32 * 255) return;
+    const int w = id / 255, d = id % 255 + 1;
+    const XYZZ<F> b = ldv(win_bases + w);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 7; bit >= 0; bit--) {
+        acc = xyzz_dbl(acc);
+        if ((d >> bit) & 1) xyzz_add(acc, b);
+    }
+    stv(table + id, xyzz_to_affine(acc));
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) fixed_base_kernel(const Affine<F> *table, const uint32_t *scalars, size_t n, Affine<F> *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < 32; w++) {
+        const uint32_t d = (scalars[8 * i + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
+        if (d) {
+            const Affine<F> p = ldv(table + w * 255 + (d - 1));
+            xyzz_madd(acc, p, false);
+        }
+    }
+    stv(out + i, xyzz_to_affine(acc));
+}
+
+// ------------------------------------------------------------------------------------------------ host drivers
+static int pick_window_bits(zkg16_ctx *ctx, size_t n) {
+    if (ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 16) return ctx->opt_window_bits;
+    int lg = 0;
+    while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
+    int c = lg - 3;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan) {
+    plan.n = n;
+    plan.c = pick_window_bits(ctx, n);
+    plan.nwin = 255 / plan.c + 1;
+    plan.nb = (size_t)1 << (plan.c - 1);
+    plan.seg_len = 64;
+    plan.total_entries = 0;
+    plan.nseg = 0;
+    if (n == 0) return;
+    const size_t tb = plan.nb * plan.nwin;
+    ws.keys.ensure(n * plan.nwin * sizeof(uint32_t));
+    ws.entries.ensure(n * plan.nwin * sizeof(uint32_t));
+    ws.counts.ensure(tb * sizeof(uint32_t));
+    ws.cursors.ensure(tb * sizeof(uint32_t));
+    ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
+    ZK_HIP(hipMemsetAsync(ws.counts.p, 0, tb * sizeof(uint32_t), ctx->stream));
+    ZK_HIP(hipMemsetAsync(ws.cursors.p, 0, tb * sizeof(uint32_t), ctx->stream));
+    {
+        ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const uint32_t *>(scalars_canonical), n, plan.c, plan.nwin, plan.nb,
+                           ws.keys.as<uint32_t>(), ws.counts.as<uint32_t>());
+    }
+    {
+        ScopedKernelTimer kt(ctx, "msm_scan_kernel", (double)tb);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ws.counts.as<uint32_t>(), ws.offsets.as<uint32_t>(), tb);
+    }
+    {
+        const size_t tot = n * (size_t)plan.nwin;
+        ScopedKernelTimer kt(ctx, "msm_scatter_kernel", (double)tot);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ws.keys.as<uint32_t>(), n, plan.nwin, plan.nb, ws.offsets.as<uint32_t>(), ws.cursors.as<uint32_t>(),
+                           ws.entries.as<uint32_t>());
+    }
+    ZK_HIP(hipGetLastError());
+    uint32_t total = 0;
+    ZK_HIP(hipMemcpyAsync(&total, ws.offsets.as<uint32_t>() + tb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    plan.total_entries = total;
+    plan.nseg = (total + plan.seg_len - 1) / plan.seg_len;
+}
+
+template <class F>
+static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, const char *tag) {
+    if (plan.n == 0 || plan.total_entries == 0) return XYZZ<F>::inf();
+    const size_t tb = plan.nb * plan.nwin;
+    const size_t psz = sizeof(XYZZ<F>);
+    ws.buckets.ensure(tb * psz);
+    ws.seg_head.ensure(plan.nseg * psz);
+    ws.seg_tail.ensure(plan.nseg * psz);
+    ws.seg_meta.ensure(plan.nseg * 2 * sizeof(int32_t));
+    ZK_HIP(hipMemsetAsync(ws.buckets.p, 0, tb * psz, ctx->stream));
+    AccArgs<F> a;
+    a.bases = bases;
+    a.entries = ws.entries.as<uint32_t>();
+    a.offsets = ws.offsets.as<uint32_t>();
+    a.buckets = ws.buckets.as<XYZZ<F>>();
+    a.seg_head = ws.seg_head.as<XYZZ<F>>();
+    a.seg_tail = ws.seg_tail.as<XYZZ<F>>();
+    a.seg_meta = ws.seg_meta.as<int32_t>();
+    a.total_entries = plan.total_entries;
+    a.total_buckets = tb;
+    a.nseg = plan.nseg;
+    a.seg_len = plan.seg_len;
+    const unsigned grid = (unsigned)((plan.nseg + 63) / 64);
+    {
+        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_accumulate_g1" : "msm_accumulate_g2", (double)plan.total_entries);
+        hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    }
+    {
+        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_g1" : "msm_fixup_g2", (double)plan.nseg);
+        hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    }
+    // weighted bucket reduction tree
+    const int kbits = 3;
+    size_t m = plan.nb;
+    int log_block = 0;
+    bool first = true;
+    const XYZZ<F> *s_in = a.buckets, *t_in = a.buckets;
+    DevBuf *bufs[4] = {&ws.lvl_a, &ws.lvl_b, &ws.lvl_c, &ws.lvl_d};
+    int flip = 0;
+    while (m > 1) {
+        const int k = m >= ((size_t)1 << kbits) ? (1 << kbits) : (int)m;
+        const size_t mo = m / k;
+        DevBuf *so = bufs[flip], *to = bufs[flip + 1];
+        so->ensure(mo * plan.nwin * psz);
+        to->ensure(mo * plan.nwin * psz);
+        ReduceArgs<F> r;
+        r.s_in = s_in; r.t_in = t_in;
+        r.s_out = so->as<XYZZ<F>>(); r.t_out = to->as<XYZZ<F>>();
+        r.m = m; r.k = k; r.log_block = log_block; r.first = first ? 1 : 0; r.nwin = plan.nwin;
+        const size_t threads = mo * plan.nwin;
+        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_reduce_level_g1" : "msm_reduce_level_g2", (double)(m * plan.nwin));
+        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, r);
+        s_in = r.s_out; t_in = r.t_out;
+        int kb = 0;
+        while ((1 << kb) < k) kb++;
+        log_block += kb;
+        m = mo;
+        first = false;
+        flip ^= 2;
+    }
+    ZK_HIP(hipGetLastError());
+    std::vector<XYZZ<F>> wsum(plan.nwin);
+    ZK_HIP(hipMemcpyAsync(wsum.data(), t_in, plan.nwin * psz, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    // host Horner over windows: sum_w 2^(c*w) W_w
+    XYZZ<F> total = wsum[plan.nwin - 1];
+    for (int w = plan.nwin - 2; w >= 0; w--) {
+        for (int q = 0; q < plan.c; q++) total = xyzz_dbl(total);
+        xyzz_add(total, wsum[w]);
+    }
+    (void)tag;
+    return total;
+}
+
+G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1Affine *bases, const char *tag) {
+    return msm_exec<Fq>(ctx, ws, plan, bases, tag);
+}
+G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2Affine *bases, const char *tag) {
+    return msm_exec<Fq2>(ctx, ws, plan, bases, tag);
+}
+
+template <class F>
+static void fixed_base_run(zkg16_ctx *ctx, const Affine<F> &base, const Fr *scalars_canonical, size_t n, Affine<F> *out) {
+    if (n == 0) return;
+    std::vector<XYZZ<F>> wb(32);
+    XYZZ<F> cur = XYZZ<F>::from_affine(base);
+    for (int w = 0; w < 32; w++) {
+        wb[w] = cur;
+        for (int q = 0; q < 8; q++) cur = xyzz_dbl(cur);
+    }
+    DevBuf d_wb(32 * sizeof(XYZZ<F>)), d_tab(32 * 255 * sizeof(Affine<F>));
+    ZK_HIP(hipMemcpyAsync(d_wb.p, wb.data(), 32 * sizeof(XYZZ<F>), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fixed_base_table_kernel<F>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<XYZZ<F>>(), d_tab.as<Affine<F>>());
+    hipLaunchKernelGGL(fixed_base_kernel<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_tab.as<Affine<F>>(),
+                       reinterpret_cast<const uint32_t *>(scalars_canonical), n, out);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+}
+void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, G1Affine *out) { fixed_base_run<Fq>(ctx, base, sc, n, out); }
+void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, G2Affine *out) { fixed_base_run<Fq2>(ctx, base, sc, n, out); }
+
+}  // namespace zk

@@ -1,0 +1,287 @@
+// BLS12-381 Fr radix-2 NTT for gfx950 — the seven transforms of the R1CS->QAP witness map
+// (ark-poly 0.4.2 Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place as driven by
+// ark-groth16 r1cs_to_qap.rs; reached from /root/reference/src/arkworks/backend/matrix_proof.rs:139-140).
+//
+// Shape: a "four-step" split N = N1 * N2 so that every butterfly stage runs out of LDS and HBM is touched
+// exactly twice per element per transform (once for N <= 2048):
+//   pass 1 (cols): for each group of C adjacent columns i2, load x[N2*i1 + i2] (C*32 B contiguous segments),
+//                  N1-point DIF in LDS, multiply by the inter-pass twiddle w_N^(i2*k1), store in place.
+//   pass 2 (rows): for each group of R adjacent rows k1, load N2 contiguous elements, N2-point DIF in LDS,
+//                  write X[k1 + N1*k2] (R*32 B contiguous segments) to the output buffer.
+// Natural order in, natural order out: the bit reversal of the DIF is absorbed by the LDS read-out.
+// LDS tile = 2048 elements, limb-major (SoA) with an XOR bank swizzle so that both the stride-h butterfly
+// accesses and the bit-reversed read-out are conflict-free; the sub-transform's twiddles (w_M^e, e < M/2) are
+// staged once per workgroup in LDS.  No MFMA: there is no dense contraction in a modular butterfly.
+// Coset shifts (g = 7) and the 1/N of the inverse ride on the load of pass 1 / the store of pass 2.
+#include "common.hpp"
+
+namespace zk {
+
+static constexpr int NTT_TILE_LOG = 11;
+static constexpr int NTT_TILE = 1 << NTT_TILE_LOG;   // elements per workgroup tile (64 KiB of LDS)
+static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_MAX_SUB_LOG = 11;           // a tile may hold one whole 2048-point sub-transform
+
+__device__ __forceinline__ int swz(int e) { return e ^ ((e >> 5) & 31); }
+
+__device__ __forceinline__ Fr lds_ld(const uint32_t *s, int stride, int e) {
+    Fr v;
+    const int p = swz(e);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v.l[k] = s[k * stride + p];
+    return v;
+}
+__device__ __forceinline__ void lds_st(uint32_t *s, int stride, int e, const Fr &v) {
+    const int p = swz(e);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k * stride + p] = v.l[k];
+}
+
+__device__ __forceinline__ Fr gld(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
+}
+__device__ __forceinline__ void gst(Fr *p, const Fr &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+__device__ __forceinline__ int bitrev(int x, int bits) { return bits == 0 ? 0 : (int)(__brev((unsigned)x) >> (32 - bits)); }
+
+struct NttPassArgs {
+    const Fr *in;
+    Fr *out;
+    const Fr *w;       // w_N^j table
+    const Fr *pre;     // optional per-input-index multiplier (coset fft), else null
+    const Fr *post;    // optional per-output-index multiplier (coset ifft), else null
+    Fr post_const;     // used when post_const_on (plain ifft: N^-1)
+    int post_const_on;
+    int log_n, log_n1, log_n2;
+    int inverse;
+};
+
+// DIF over `ncols` independent sub-transforms of size 2^log_m laid out back to back in the LDS tile.
+__device__ __forceinline__ void lds_dif(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride) {
+    const int tid = threadIdx.x;
+    for (int s = log_m - 1; s >= 0; s--) {
+        const int h = 1 << s;
+        for (int u = tid; u < NTT_TILE / 2; u += NTT_THREADS) {
+            const int c = u >> (log_m - 1);
+            const int v = u & ((1 << (log_m - 1)) - 1);
+            const int j = v & (h - 1);
+            const int blk = v >> s;
+            const int i0 = (c << log_m) + (blk << (s + 1)) + j;
+            const int i1 = i0 + h;
+            Fr a = lds_ld(s_data, NTT_TILE, i0);
+            Fr b = lds_ld(s_data, NTT_TILE, i1);
+            Fr sum = fp_add(a, b);
+            Fr dif = fp_sub(a, b);
+            if (s > 0) {   // the last stage's twiddle is w^0 = 1
+                Fr tw = lds_ld(s_tw, tw_stride, j << (log_m - 1 - s));
+                dif = fp_mul(dif, tw);
+            }
+            lds_st(s_data, NTT_TILE, i0, sum);
+            lds_st(s_data, NTT_TILE, i1, dif);
+        }
+        __syncthreads();
+    }
+}
+
+// twiddles of the 2^log_m sub-transform: w_M^e = w_N^(e * N/M), e < M/2 (inverse: w_N^-(...) = w[N - ...])
+__device__ __forceinline__ void stage_twiddles(uint32_t *s_tw, int tw_stride, const Fr *w, int log_n, int log_m, int inverse) {
+    const int half = 1 << (log_m > 0 ? log_m - 1 : 0);
+    const unsigned nmask = (1u << log_n) - 1u;
+    for (int e = threadIdx.x; e < half; e += NTT_THREADS) {
+        unsigned idx = (unsigned)e << (log_n - log_m);
+        if (inverse) idx = ((1u << log_n) - idx) & nmask;
+        lds_st(s_tw, tw_stride, e, gld(w + idx));
+    }
+}
+
+// pass 1: column groups.  grid = N2 / C, C = TILE >> log_n1.
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_data = smem;                         // [8][TILE]
+    uint32_t *s_tw = smem + 8 * NTT_TILE;            // [8][tw_stride]
+    const int tw_stride = 1 << (a.log_n1 - 1);
+    const int n1 = 1 << a.log_n1;
+    const int log_c = NTT_TILE_LOG - a.log_n1;
+    const int C = 1 << log_c;
+    const unsigned nmask = (1u << a.log_n) - 1u;
+    const size_t n2 = (size_t)1 << a.log_n2;
+    const size_t col0 = (size_t)blockIdx.x * C;
+
+    stage_twiddles(s_tw, tw_stride, a.w, a.log_n, a.log_n1, a.inverse);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
+        const int c = t & (C - 1), i1 = t >> log_c;
+        const size_t gi = (size_t)i1 * n2 + col0 + c;
+        Fr v = gld(a.in + gi);
+        if (a.pre) v = fp_mul(v, gld(a.pre + gi));
+        lds_st(s_data, NTT_TILE, (c << a.log_n1) + i1, v);
+    }
+    __syncthreads();
+    lds_dif(s_data, s_tw, a.log_n1, tw_stride);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
+        const int c = t & (C - 1), k1 = t >> log_c;
+        Fr v = lds_ld(s_data, NTT_TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
+        const size_t i2 = col0 + c;
+        unsigned e = (unsigned)((i2 * (size_t)k1) & nmask);    // inter-pass twiddle w_N^(i2*k1)
+        if (a.inverse) e = ((1u << a.log_n) - e) & nmask;
+        if (e) v = fp_mul(v, gld(a.w + e));
+        gst(a.out + (size_t)k1 * n2 + i2, v);
+    }
+    (void)n1;
+}
+
+// pass 2: row groups.  grid = N1 / R, R = TILE >> log_n2.  Also the whole transform when log_n1 == 0.
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_data = smem;
+    uint32_t *s_tw = smem + 8 * NTT_TILE;
+    const int tw_stride = a.log_n2 > 0 ? 1 << (a.log_n2 - 1) : 1;
+    const int log_r = NTT_TILE_LOG - a.log_n2;
+    const int R = 1 << log_r;
+    const size_t n1 = (size_t)1 << a.log_n1;
+    const size_t n2 = (size_t)1 << a.log_n2;
+    const size_t row0 = (size_t)blockIdx.x * R;
+    const size_t n1_rows = n1;                        // rows that exist (R may exceed N1 for tiny transforms)
+
+    stage_twiddles(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
+        const int i2 = t & ((1 << a.log_n2) - 1), r = t >> a.log_n2;
+        Fr v = Fr::zero();
+        if (row0 + r < n1_rows) {
+            const size_t gi = (row0 + r) * n2 + i2;
+            v = gld(a.in + gi);
+            if (a.pre) v = fp_mul(v, gld(a.pre + gi));
+        }
+        lds_st(s_data, NTT_TILE, t, v);
+    }
+    __syncthreads();
+    lds_dif(s_data, s_tw, a.log_n2, tw_stride);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
+        const int r = t & (R - 1), k2 = t >> log_r;
+        if (row0 + r >= n1_rows) continue;
+        Fr v = lds_ld(s_data, NTT_TILE, (r << a.log_n2) + bitrev(k2, a.log_n2));
+        const size_t k = (row0 + r) + n1 * (size_t)k2;
+        if (a.post) v = fp_mul(v, gld(a.post + k));
+        else if (a.post_const_on) v = fp_mul(v, a.post_const);
+        gst(a.out + k, v);
+    }
+}
+
+// out[i] = scale * base^i
+__global__ void fr_powers_kernel(Fr *out, Fr base, Fr scale, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gst(out + i, fp_mul(fp_pow_u64(base, (uint64_t)i), scale));
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static Fr fr_from_u64_host(uint64_t v) {
+    Fr c = Fr::zero();
+    c.l[0] = (uint32_t)v;
+    c.l[1] = (uint32_t)(v >> 32);
+    return fp_to_mont(c);
+}
+
+NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
+    auto it = ctx->ntt_tables.find(log_n);
+    if (it != ctx->ntt_tables.end()) return it->second.get();
+    auto t = std::make_unique<NttTables>();
+    t->log_n = log_n;
+    const size_t n = (size_t)1 << log_n;
+    // 2^32-th root of unity 7^((r-1)/2^32) (Montgomery), squared down to order N
+    Fr root;
+    {
+        const uint32_t R32[8] = {0x5f0e466au, 0xb9b58d8cu, 0x1819d7ecu, 0x5b1b4c80u, 0x52a31e64u, 0x0af53ae3u, 0x19e9b27bu, 0x5bf3addau};
+        for (int i = 0; i < 8; i++) root.l[i] = R32[i];
+        for (int i = log_n; i < 32; i++) root = fp_sqr(root);
+    }
+    const Fr g = fr_from_u64_host(7);
+    const Fr g_inv = fp_inv(g);
+    t->n_inv = fp_inv(fr_from_u64_host((uint64_t)n));
+    Fr gn = g;
+    for (int i = 0; i < log_n; i++) gn = fp_sqr(gn);
+    t->zinv = fp_inv(fp_sub(gn, Fr::one()));
+    t->w.alloc(n * sizeof(Fr));
+    t->g.alloc(n * sizeof(Fr));
+    t->gi.alloc(n * sizeof(Fr));
+    const int bs = 256;
+    const unsigned grid = (unsigned)((n + bs - 1) / bs);
+    hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->w.as<Fr>(), root, Fr::one(), n);
+    hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->g.as<Fr>(), g, Fr::one(), n);
+    hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->gi.as<Fr>(), g_inv, t->n_inv, n);
+    ZK_HIP(hipGetLastError());
+    NttTables *raw = t.get();
+    ctx->ntt_tables[log_n] = std::move(t);
+    return raw;
+}
+
+// In-place from the caller's view: the result ends in `data`; `tmp` (N elements) is scratch.
+void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset) {
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // 64 KiB tile + up to 32 KiB of twiddles: above the 64 KiB default dynamic-LDS cap
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_set = true;
+    }
+    if (log_n > 2 * NTT_MAX_SUB_LOG) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^22", __FILE__, __LINE__};
+    NttTables *t = ntt_get_tables(ctx, log_n);
+    const size_t n = (size_t)1 << log_n;
+    NttPassArgs a;
+    memset(&a, 0, sizeof a);
+    a.w = t->w.as<Fr>();
+    a.log_n = log_n;
+    a.inverse = inverse ? 1 : 0;
+    const Fr *pre = (!inverse && coset) ? t->g.as<Fr>() : nullptr;
+    const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
+    const int post_const_on = (inverse && !coset) ? 1 : 0;
+    a.post_const = t->n_inv;
+
+    if (log_n <= NTT_MAX_SUB_LOG) {
+        a.log_n1 = 0;
+        a.log_n2 = log_n;
+        a.in = data;
+        a.out = tmp;
+        a.pre = pre;
+        a.post = post;
+        a.post_const_on = post_const_on;
+        const size_t lds = (size_t)8 * 4 * (NTT_TILE + (log_n > 0 ? (1 << (log_n - 1)) : 1));
+        ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
+        hipLaunchKernelGGL(ntt_pass_rows, dim3(1), dim3(NTT_THREADS), lds, ctx->stream, a);
+    } else {
+        a.log_n2 = log_n / 2;
+        a.log_n1 = log_n - a.log_n2;
+        {
+            NttPassArgs p1 = a;
+            p1.in = data;
+            p1.out = data;
+            p1.pre = pre;
+            const size_t lds = (size_t)8 * 4 * (NTT_TILE + (1 << (a.log_n1 - 1)));
+            const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (NTT_TILE_LOG - a.log_n1));
+            ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
+            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid), dim3(NTT_THREADS), lds, ctx->stream, p1);
+        }
+        {
+            NttPassArgs p2 = a;
+            p2.in = data;
+            p2.out = tmp;
+            p2.post = post;
+            p2.post_const_on = post_const_on;
+            const size_t lds = (size_t)8 * 4 * (NTT_TILE + (1 << (a.log_n2 - 1)));
+            const unsigned grid = (unsigned)(((size_t)1 << a.log_n1) >> (NTT_TILE_LOG - a.log_n2));
+            ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
+            hipLaunchKernelGGL(ntt_pass_rows, dim3(grid), dim3(NTT_THREADS), lds, ctx->stream, p2);
+        }
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(data, tmp, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+}  // namespace zk

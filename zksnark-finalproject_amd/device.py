@@ -1,0 +1,198 @@
+"""Thin object layer over the C ABI: one `Device` == one zkg16_ctx == one MI355X."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Zkg16Error
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _opt_u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Device:
+    def __init__(self, device_id=0):
+        self.lib = _lib.load()
+        self.ctx = C.c_void_p()
+        ids = (C.c_int * 1)(device_id)
+        rc = self.lib.zkg16_init(ids, 1, C.byref(self.ctx))
+        if rc != 0:
+            raise Zkg16Error(rc, self.lib.zkg16_strerror(rc).decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.zkg16_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            detail = self.lib.zkg16_last_error(self.ctx).decode()
+            raise Zkg16Error(rc, self.lib.zkg16_strerror(rc).decode() + (" — " + detail if detail else ""))
+
+    # ---- residency
+    def pk_load(self, pk, num_instance, shard_index=0, shard_count=1):
+        """pk: dict of numpy arrays (see groth16.ProvingKey.as_arrays)."""
+        a, b1, b2 = _u64(pk["a_query"]).reshape(-1, 12), _u64(pk["b_g1_query"]).reshape(-1, 12), _u64(pk["b_g2_query"]).reshape(-1, 24)
+        h, l = _u64(pk["h_query"]).reshape(-1, 12), _u64(pk["l_query"]).reshape(-1, 12)
+        infs = [_opt_u8(pk.get(k)) for k in ("a_inf", "b_g1_inf", "b_g2_inf", "h_inf", "l_inf")]
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_pk_load(
+            self.ctx, a, _ptr(infs[0]), a.shape[0], b1, _ptr(infs[1]), b1.shape[0], b2, _ptr(infs[2]), b2.shape[0],
+            _ptr(h), _ptr(infs[3]), h.shape[0], _ptr(l), _ptr(infs[4]), l.shape[0],
+            _u64(pk["alpha_g1"]), _u64(pk["beta_g1"]), _u64(pk["beta_g2"]), _u64(pk["delta_g1"]), _u64(pk["delta_g2"]),
+            num_instance, shard_index, shard_count, C.byref(handle)))
+        return handle.value
+
+    def pk_free(self, h):
+        self.lib.zkg16_pk_free(self.ctx, h)
+
+    @staticmethod
+    def _csr(r1cs):
+        args, keep = [], []
+        for m in ("a", "b", "c"):
+            rp, col, cf = r1cs[m]
+            rp = _u64(rp)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            cf = _u64(cf).reshape(-1, 4)
+            keep += [rp, col, cf]
+            args += [rp, _ptr(col) if col.size else None, _ptr(cf) if cf.size else None]
+        return args, keep
+
+    def r1cs_load(self, r1cs, num_variables):
+        args, keep = self._csr(r1cs)
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_r1cs_load(self.ctx, *args, r1cs["num_inputs"], r1cs["num_constraints"], num_variables, C.byref(handle)))
+        return handle.value
+
+    def r1cs_free(self, h):
+        self.lib.zkg16_r1cs_free(self.ctx, h)
+
+    def witness_load(self, z):
+        z = _u64(z).reshape(-1, 4)
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_witness_load(self.ctx, z, z.shape[0], C.byref(handle)))
+        return handle.value
+
+    def witness_free(self, h):
+        self.lib.zkg16_witness_free(self.ctx, h)
+
+    # ---- proofs
+    def prove_resident(self, pk_h, r1cs_h, wit_h, r, s):
+        proof = np.zeros(48, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        self._check(self.lib.zkg16_prove_resident(self.ctx, pk_h, r1cs_h, wit_h, _u64(r), _u64(s), proof, inf))
+        return proof, inf
+
+    def prove(self, pk_h, r, s, r1cs, z):
+        args, keep = self._csr(r1cs)
+        z = _u64(z).reshape(-1, 4)
+        proof = np.zeros(48, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        self._check(self.lib.zkg16_prove(self.ctx, pk_h, _u64(r), _u64(s), *args, r1cs["num_inputs"], r1cs["num_constraints"],
+                                         z, z.shape[0], proof, inf))
+        return proof, inf
+
+    def prove_partial(self, pk_h, r1cs_h, wit_h, r, s):
+        part = np.zeros(72, dtype=np.uint64)
+        inf = np.zeros(5, dtype=np.uint8)
+        self._check(self.lib.zkg16_prove_partial(self.ctx, pk_h, r1cs_h, wit_h, _u64(r), _u64(s), part, inf))
+        return part, inf
+
+    def prove_finish(self, pk_h, r, s, partials, partial_inf):
+        partials = _u64(partials).reshape(-1, 72)
+        partial_inf = np.ascontiguousarray(partial_inf, dtype=np.uint8).reshape(-1, 5)
+        proof = np.zeros(48, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        self._check(self.lib.zkg16_prove_finish(self.ctx, pk_h, _u64(r), _u64(s), partials, partial_inf, partials.shape[0], proof, inf))
+        return proof, inf
+
+    # ---- stages
+    def ntt(self, data, inverse=False, coset=False):
+        d = _u64(data).reshape(-1, 4).copy()
+        n = d.shape[0]
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        self._check(self.lib.zkg16_ntt(self.ctx, d, log_n, int(inverse), int(coset)))
+        return d
+
+    def msm(self, group, bases, scalars_canonical, inf=None):
+        w = 12 if group == "g1" else 24
+        bases = _u64(bases).reshape(-1, w)
+        sc = _u64(scalars_canonical).reshape(-1, 4)
+        n = min(bases.shape[0], sc.shape[0])
+        inf = _opt_u8(inf)
+        out = np.zeros(w, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        fn = self.lib.zkg16_msm_g1 if group == "g1" else self.lib.zkg16_msm_g2
+        self._check(fn(self.ctx, _ptr(bases) if n else None, _ptr(inf), _ptr(sc) if n else None, n, out, oinf))
+        return out, int(oinf[0])
+
+    def bench_msm(self, group, bases, scalars_canonical, iters=3, inf=None):
+        w = 12 if group == "g1" else 24
+        bases = _u64(bases).reshape(-1, w)
+        sc = _u64(scalars_canonical).reshape(-1, 4)
+        n = min(bases.shape[0], sc.shape[0])
+        inf = _opt_u8(inf)
+        out = np.zeros(w, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        ms = C.c_float()
+        self._check(self.lib.zkg16_bench_msm(self.ctx, 1 if group == "g1" else 2, _ptr(bases), _ptr(inf), _ptr(sc), n, iters,
+                                             C.byref(ms), out, oinf))
+        return ms.value, out, int(oinf[0])
+
+    def bench_ntt(self, log_n, inverse=False, coset=False, iters=10):
+        ms = C.c_float()
+        self._check(self.lib.zkg16_bench_ntt(self.ctx, log_n, int(inverse), int(coset), iters, C.byref(ms)))
+        return ms.value
+
+    def witness_map(self, r1cs_h, wit_h, n_max):
+        h = np.zeros((n_max, 4), dtype=np.uint64)
+        log_n = C.c_size_t()
+        self._check(self.lib.zkg16_witness_map(self.ctx, r1cs_h, wit_h, h, C.byref(log_n)))
+        return h[: 1 << log_n.value]
+
+    def fixed_base(self, group, base, scalars_canonical):
+        w = 12 if group == "g1" else 24
+        sc = _u64(scalars_canonical).reshape(-1, 4)
+        n = sc.shape[0]
+        out = np.zeros((n, w), dtype=np.uint64)
+        oinf = np.zeros(n, dtype=np.uint8)
+        fn = self.lib.zkg16_fixed_base_g1 if group == "g1" else self.lib.zkg16_fixed_base_g2
+        self._check(fn(self.ctx, _u64(base), _ptr(sc), n, _ptr(out), _ptr(oinf)))
+        return out, oinf
+
+    # ---- instrumentation
+    def last_timings(self):
+        buf = (C.c_float * 10)()
+        n = self.lib.zkg16_last_timings(self.ctx, buf, 10)
+        names = ["spmv", "witness_map", "msm_sort", "msm_h", "msm_l", "msm_a", "msm_b1", "msm_b2", "host_tail", "total_wall"]
+        return {names[i]: float(buf[i]) for i in range(n)}
+
+    def kernel_timing(self, enable=True):
+        self._check(self.lib.zkg16_kernel_timing(self.ctx, int(enable)))
+
+    def kernel_stats(self, name):
+        launches, ms, units = C.c_uint64(), C.c_double(), C.c_double()
+        self._check(self.lib.zkg16_kernel_stats(self.ctx, name.encode(), C.byref(launches), C.byref(ms), C.byref(units)))
+        return dict(launches=launches.value, ms=ms.value, units=units.value)
+
+    def kernel_stats_reset(self):
+        self.lib.zkg16_kernel_stats_reset(self.ctx)
+
+    def set_option(self, name, value):
+        self._check(self.lib.zkg16_set_option(self.ctx, name.encode(), int(value)))
