@@ -106,6 +106,14 @@ ZKG16_API int zkg16_prove_finish(zkg16_ctx *ctx, uint64_t pk_handle, const uint6
                        const uint64_t *partials /* n_ranks x 72 */, const uint8_t *partial_inf /* n_ranks x 5 */,
                        int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]);
 
+/* Host-only form of the finish step (no ctx, no GPU): sums the per-rank partial records and applies the proof
+ * tail  A = alpha + sum A_k,  B = beta2 + sum B2_k,  C = s*A + r*(beta1 + sum B1_k) + sum L_k + sum H_k.
+ * (r*delta1, s*delta1, s*delta2 and -rs*delta1 already ride inside rank 0's partials as extra MSM terms.) */
+ZKG16_API int zkg16_combine_partials(const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                           const uint64_t r[4], const uint64_t s[4],
+                           const uint64_t *partials /* n_ranks x 72 */, const uint8_t *partial_inf /* n_ranks x 5 */,
+                           int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]);
+
 /* ---- stage entry points (tests / bench; host buffers) ----------------------------------------- */
 /* ark-poly Radix2EvaluationDomain<Fr>: in-place, natural order; inverse => ifft (incl. 1/N);
  * coset => offset g = 7 (coset_fft = g^i then fft; coset_ifft = ifft then g^-i). */

@@ -72,3 +72,7 @@ def expected_proof_logs(meta, logs_int, h_int, z_int, num_inputs, r, s):
     L = dict(a_query=logs_int["a"], b_query=logs_int["b"], l_query=logs_int["l"], h_query=logs_int["h"],
              gamma_abc=logs_int["gabc"], alpha=t["alpha"], beta=t["beta"], gamma=t["gamma"], delta=t["delta"])
     return P.groth16_prove_logs(L, h_int, z_int, num_inputs, r, s)
+
+
+
+from zksnark_finalproject_amd.workloads import matmul_like_r1cs, matmul_shape  # noqa: E402,F401

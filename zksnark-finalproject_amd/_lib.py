@@ -37,6 +37,7 @@ SIGNATURES = {
     "zkg16_prove": (C.c_int, [ctxp, H, u64p, u64p] + [u64p, vp, vp] * 3 + [sz, sz, u64p, sz, u64p, u8p]),
     "zkg16_prove_partial": (C.c_int, [ctxp, H, H, H, u64p, u64p, u64p, u8p]),
     "zkg16_prove_finish": (C.c_int, [ctxp, H, u64p, u64p, u64p, u8p, C.c_int, u64p, u8p]),
+    "zkg16_combine_partials": (C.c_int, [u64p, u64p, u64p, u64p, u64p, u64p, u8p, C.c_int, u64p, u8p]),
     "zkg16_ntt": (C.c_int, [ctxp, u64p, sz, C.c_int, C.c_int]),
     "zkg16_msm_g1": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),
     "zkg16_msm_g2": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),

@@ -10,6 +10,36 @@
 
 using namespace zk;
 
+namespace zk {
+ScopedKernelTimer::ScopedKernelTimer(zkg16_ctx *c, const char *n, double u) : ctx(c), name(n), units(u) {
+    if (!ctx->kernel_timing) return;
+    ZK_HIP(hipEventCreate(&e0));
+    ZK_HIP(hipEventCreate(&e1));
+    ZK_HIP(hipEventRecord(e0, ctx->stream));
+}
+ScopedKernelTimer::~ScopedKernelTimer() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->pending_events.push_back(PendingEvent{name, units, e0, e1});
+}
+void kernel_timer_resolve(zkg16_ctx *ctx) {
+    if (ctx->pending_events.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            auto &s = ctx->kstats[p.name];
+            s.launches++;
+            s.ms += ms;
+            s.units += p.units;
+        }
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    ctx->pending_events.clear();
+}
+}  // namespace zk
+
 namespace {
 
 const char *k_version = "zkg16 0.1 (gfx950; BLS12-381 Groth16 prove hot path)";
@@ -173,13 +203,14 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
 
 // Host tail (a9): A = alpha + MSM_a, B = beta + MSM_b, C = s*A + r*B1 + MSM_l + MSM_h.
 // (r*delta, s*delta and -rs*delta already ride inside the MSMs as three extra (base, scalar) slots.)
-void prove_tail(PkDev &pk, const Fr &r, const Fr &s, const Partials &p, uint64_t *proof_out, uint8_t *inf_out) {
+void prove_tail_pts(const G1Affine &alpha_g1, const G1Affine &beta_g1, const G2Affine &beta_g2, const Fr &r, const Fr &s,
+                    const Partials &p, uint64_t *proof_out, uint8_t *inf_out) {
     G1XYZZ A = p.a;
-    xyzz_madd(A, pk.alpha_g1, false);
+    xyzz_madd(A, alpha_g1, false);
     G1XYZZ B1 = p.b1;
-    xyzz_madd(B1, pk.beta_g1, false);
+    xyzz_madd(B1, beta_g1, false);
     G2XYZZ B2 = p.b2;
-    xyzz_madd(B2, pk.beta_g2, false);
+    xyzz_madd(B2, beta_g2, false);
     const Fr rc = fp_from_mont(r), sc = fp_from_mont(s);
     G1XYZZ C = xyzz_mul(A, sc.l);
     G1XYZZ rB = xyzz_mul(B1, rc.l);
@@ -190,6 +221,11 @@ void prove_tail(PkDev &pk, const Fr &r, const Fr &s, const Partials &p, uint64_t
     point_to_abi(xyzz_to_affine(B2), proof_out + 12, inf_out + 1);
     point_to_abi(xyzz_to_affine(C), proof_out + 36, inf_out + 2);
 }
+void prove_tail(PkDev &pk, const Fr &r, const Fr &s, const Partials &p, uint64_t *proof_out, uint8_t *inf_out) {
+    prove_tail_pts(pk.alpha_g1, pk.beta_g1, pk.beta_g2, r, s, p, proof_out, inf_out);
+}
+
+void sum_partials(Partials &p, const uint64_t *partials, const uint8_t *partial_inf, int n_ranks);
 
 Fr fr_from_abi(const uint64_t *l) {
     Fr v;
@@ -230,6 +266,20 @@ int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const
     *handle = ctx->next_handle++;
     ctx->r1cs[*handle] = std::move(r);
     return ZKG16_OK;
+}
+
+void sum_partials(Partials &p, const uint64_t *partials, const uint8_t *partial_inf, int n_ranks) {
+    p.h = p.l = p.a = p.b1 = G1XYZZ::inf();
+    p.b2 = G2XYZZ::inf();
+    for (int k = 0; k < n_ranks; k++) {
+        const uint64_t *q = partials + 72 * (size_t)k;
+        const uint8_t *f = partial_inf + 5 * (size_t)k;
+        xyzz_madd(p.h, g1_from_abi(q, f[0]), false);
+        xyzz_madd(p.l, g1_from_abi(q + 12, f[1]), false);
+        xyzz_madd(p.a, g1_from_abi(q + 24, f[2]), false);
+        xyzz_madd(p.b1, g1_from_abi(q + 36, f[3]), false);
+        xyzz_madd(p.b2, g2_from_abi(q + 48, f[4]), false);
+    }
 }
 
 }  // namespace
@@ -443,19 +493,21 @@ int zkg16_prove_finish(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], 
     PkDev *pk = find_handle(ctx->pks, pk_handle);
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
     Partials p;
-    p.h = p.l = p.a = p.b1 = G1XYZZ::inf();
-    p.b2 = G2XYZZ::inf();
-    for (int k = 0; k < n_ranks; k++) {
-        const uint64_t *q = partials + 72 * (size_t)k;
-        const uint8_t *f = partial_inf + 5 * (size_t)k;
-        xyzz_madd(p.h, g1_from_abi(q, f[0]), false);
-        xyzz_madd(p.l, g1_from_abi(q + 12, f[1]), false);
-        xyzz_madd(p.a, g1_from_abi(q + 24, f[2]), false);
-        xyzz_madd(p.b1, g1_from_abi(q + 36, f[3]), false);
-        xyzz_madd(p.b2, g2_from_abi(q + 48, f[4]), false);
-    }
+    sum_partials(p, partials, partial_inf, n_ranks);
     prove_tail(*pk, fr_from_abi(r), fr_from_abi(s), p, proof_out, inf_out);
     ZK_API_END(ctx)
+}
+
+int zkg16_combine_partials(const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                           const uint64_t r[4], const uint64_t s[4], const uint64_t *partials, const uint8_t *partial_inf,
+                           int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]) {
+    if (!alpha_g1 || !beta_g1 || !beta_g2 || !r || !s || !partials || !partial_inf || n_ranks < 1 || !proof_out || !inf_out)
+        return ZKG16_ERR_BAD_ARG;
+    Partials p;
+    sum_partials(p, partials, partial_inf, n_ranks);
+    prove_tail_pts(g1_from_abi(alpha_g1, 0), g1_from_abi(beta_g1, 0), g2_from_abi(beta_g2, 0), fr_from_abi(r), fr_from_abi(s), p,
+                   proof_out, inf_out);
+    return ZKG16_OK;
 }
 
 int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
@@ -658,6 +710,8 @@ int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {
 int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms, double *units) {
     if (!ctx || !kernel_name) return ZKG16_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    kernel_timer_resolve(ctx);
     auto it = ctx->kstats.find(kernel_name);
     if (it == ctx->kstats.end()) {
         if (launches) *launches = 0;
@@ -674,6 +728,8 @@ int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launch
 void zkg16_kernel_stats_reset(zkg16_ctx *ctx) {
     if (!ctx) return;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    kernel_timer_resolve(ctx);
     ctx->kstats.clear();
 }
 

@@ -57,6 +57,7 @@ struct DevBuf {
 
 // Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg reads these).
 struct KernelStat { uint64_t launches = 0; double ms = 0, units = 0; };
+struct PendingEvent;
 
 struct NttTables {          // per domain size, built on device on first use
     int log_n = 0;
@@ -89,7 +90,7 @@ struct R1csDev {
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars;
+    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list;
 };
 
 }  // namespace zk
@@ -110,39 +111,26 @@ struct zkg16_ctx {
     float timings[16] = {0};
     bool kernel_timing = false;
     std::map<std::string, zk::KernelStat> kstats;
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
     int num_cus = 256;
 };
 
 namespace zk {
 
-// Brackets one kernel launch with HIP events when ctx->kernel_timing is on.
+// Brackets one kernel launch with a HIP-event pair on the ctx stream when ctx->kernel_timing is on.
+// Recording is asynchronous (no host sync inside the timed region); pairs are resolved when stats are read.
+struct PendingEvent { std::string name; double units; hipEvent_t e0, e1; };
+
 struct ScopedKernelTimer {
     zkg16_ctx *ctx;
     const char *name;
     double units;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ScopedKernelTimer(zkg16_ctx *c, const char *n, double u) : ctx(c), name(n), units(u) {
-        if (!ctx->kernel_timing) return;
-        ZK_HIP(hipEventCreate(&e0));
-        ZK_HIP(hipEventCreate(&e1));
-        ZK_HIP(hipEventRecord(e0, ctx->stream));
-    }
-    ~ScopedKernelTimer() {
-        if (!e0) return;
-        (void)hipEventRecord(e1, ctx->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        auto &s = ctx->kstats[name];
-        s.launches++;
-        s.ms += ms;
-        s.units += units;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
+    ScopedKernelTimer(zkg16_ctx *c, const char *n, double u);
+    ~ScopedKernelTimer();
 };
+void kernel_timer_resolve(zkg16_ctx *ctx);
 
 // ---- entry points implemented per translation unit
 void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset);   // result left in `data`

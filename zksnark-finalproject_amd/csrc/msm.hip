@@ -53,6 +53,24 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars
     const uint4 *q = reinterpret_cast<const uint4 *>(scalars + 8 * i);
     uint4 lo = q[0], hi = q[1];
     s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w; s[8] = 0;
+    // scalars above (r-1)/2 are replaced by r - s with the sign of every digit flipped: the magnitude then fits 254
+    // bits, so the top window never carries out and no carry-only window (one giant bucket) exists.
+    constexpr uint32_t RH[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};  // (r-1)/2
+    bool flip = false;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        if (s[k] != RH[k]) { flip = s[k] > RH[k]; break; }
+    }
+    if (flip) {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t t = (uint64_t)FrP::mod(k) - s[k] - borrow;
+            s[k] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+        }
+    }
+    const uint32_t flipbit = flip ? 1u : 0u;
     uint32_t carry = 0;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
     for (int w = 0; w < nwin; w++) {
@@ -69,9 +87,9 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars
         if (v > half) {                       // recenter: d = v - 2^c <= 0, carry into the next window
             const uint32_t mag = (1u << c) - v;
             carry = 1;
-            if (mag) key = 1u + (((mag - 1u) << 1) | 1u);
+            if (mag) key = 1u + (((mag - 1u) << 1) | (1u ^ flipbit));
         } else if (v != 0) {
-            key = 1u + ((v - 1u) << 1);
+            key = 1u + (((v - 1u) << 1) | flipbit);
         }
         keys[(size_t)w * n + i] = key;
         if (key) atomicAdd(&counts[(size_t)w * nb + ((key - 1u) >> 1)], 1u);
@@ -170,18 +188,60 @@ __global__ void __launch_bounds__(64) msm_accumulate_kernel(AccArgs<F> a) {
 }
 
 // One lane per segment whose last bucket spills over: add the head partials of the following segments.
+// Chains longer than FIXUP_SHORT segments (a bucket holding thousands of terms: the value-1 scalars of the
+// reference's witnesses) are queued for msm_fixup_long, which gives each a whole workgroup.
+static constexpr int FIXUP_SHORT = 4;
+
 template <class F>
-__global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a) {
+__global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *long_list, uint32_t *long_count) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.nseg) return;
     const int32_t g = a.seg_meta[2 * t + 1];
     if (g < 0) return;
+    const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)a.seg_len;   // segment holding the bucket's last term
+    if (last_seg - t > FIXUP_SHORT) {
+        long_list[atomicAdd(long_count, 1u)] = (uint32_t)t;
+        return;
+    }
     XYZZ<F> sum = ldv(a.seg_tail + t);
-    for (size_t u = t + 1; u < a.nseg && a.seg_meta[2 * u] == g; u++) {
+    for (size_t u = t + 1; u <= last_seg; u++) {
         const XYZZ<F> h = ldv(a.seg_head + u);
         xyzz_add(sum, h);
     }
     stv(a.buckets + g, sum);
+}
+
+// One 256-lane workgroup per long chain (grid-stride over the queue): lanes stride over the chain's head partials,
+// then a log-depth LDS tree folds the 256 lane sums.
+template <class F>
+__global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, const uint32_t *long_list, const uint32_t *long_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fix_smem[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(fix_smem);
+    const uint32_t n_long = *long_count;
+    for (uint32_t item = blockIdx.x; item < n_long; item += gridDim.x) {
+        const size_t t = long_list[item];
+        const int32_t g = a.seg_meta[2 * t + 1];
+        const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)a.seg_len;
+        XYZZ<F> sum = XYZZ<F>::inf();
+        if (threadIdx.x == 0) sum = ldv(a.seg_tail + t);
+        for (size_t u = t + 1 + threadIdx.x; u <= last_seg; u += blockDim.x) {
+            const XYZZ<F> h = ldv(a.seg_head + u);
+            xyzz_add(sum, h);
+        }
+        sh[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) {
+                XYZZ<F> x = sh[threadIdx.x];
+                const XYZZ<F> y = sh[threadIdx.x + d];
+                xyzz_add(x, y);
+                sh[threadIdx.x] = x;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) stv(a.buckets + g, sh[0]);
+        __syncthreads();
+    }
 }
 
 // A bucket that begins exactly at a segment start and spans it entirely is recorded as that segment's HEAD
@@ -263,18 +323,21 @@ __global__ void __launch_bounds__(64) fixed_base_kernel(const Affine<F> *table, 
 // ------------------------------------------------------------------------------------------------ host drivers
 static int pick_window_bits(zkg16_ctx *ctx, size_t n) {
     if (ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 16) return ctx->opt_window_bits;
+    // 254-bit magnitudes: c = 16 and 15 leave a 14-bit top window, 13 a 7-bit one (c = 14 would leave 2 bits = 4 giant buckets)
+    if (n >= ((size_t)1 << 20)) return 16;
+    if (n >= ((size_t)1 << 17)) return 15;
+    if (n >= ((size_t)1 << 14)) return 13;
     int lg = 0;
     while (((size_t)2 << lg) <= n) lg++;          // floor(log2 n)
     int c = lg - 3;
     if (c < 4) c = 4;
-    if (c > 16) c = 16;
     return c;
 }
 
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan) {
     plan.n = n;
     plan.c = pick_window_bits(ctx, n);
-    plan.nwin = 255 / plan.c + 1;
+    plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
     plan.nb = (size_t)1 << (plan.c - 1);
     plan.seg_len = 64;
     plan.total_entries = 0;
@@ -341,8 +404,22 @@ static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
         hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
     }
     {
-        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_g1" : "msm_fixup_g2", (double)plan.nseg);
-        hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        ws.long_list.ensure((plan.nseg + 1) * sizeof(uint32_t));
+        uint32_t *long_list = ws.long_list.as<uint32_t>() + 1, *long_count = ws.long_list.as<uint32_t>();
+        ZK_HIP(hipMemsetAsync(long_count, 0, sizeof(uint32_t), ctx->stream));
+        {
+            ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_g1" : "msm_fixup_g2", (double)plan.nseg);
+            hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a, long_list, long_count);
+        }
+        static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 384 B > the 64 KiB default for G2
+        if (!lds_attr_set) {
+            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            lds_attr_set = true;
+        }
+        {
+            ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_long_g1" : "msm_fixup_long_g2", 0.0);
+            hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, ctx->stream, a, long_list, long_count);
+        }
     }
     // weighted bucket reduction tree
     const int kbits = 3;

@@ -196,3 +196,17 @@ class Device:
 
     def set_option(self, name, value):
         self._check(self.lib.zkg16_set_option(self.ctx, name.encode(), int(value)))
+
+
+def combine_partials(alpha_g1, beta_g1, beta_g2, r, s, partials, partial_inf):
+    """Host-only finish step (no GPU): see zkg16_combine_partials in include/zkg16.h."""
+    lib = _lib.load()
+    partials = _u64(partials).reshape(-1, 72)
+    partial_inf = np.ascontiguousarray(partial_inf, dtype=np.uint8).reshape(-1, 5)
+    proof = np.zeros(48, dtype=np.uint64)
+    inf = np.zeros(3, dtype=np.uint8)
+    rc = lib.zkg16_combine_partials(_u64(alpha_g1), _u64(beta_g1), _u64(beta_g2), _u64(r), _u64(s), partials, partial_inf,
+                                    partials.shape[0], proof, inf)
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return proof, inf
