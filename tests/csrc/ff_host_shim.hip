@@ -43,3 +43,49 @@ void ht_fr_from_mont(const uint32_t *a, uint32_t *o) { st(o, fp_from_mont(ld<Fr>
 void ht_g1_op(int op, const uint32_t *acc, const uint32_t *q, const uint32_t *k, int neg, uint32_t *ox, uint32_t *oa) { point_op<Fq>(op, acc, q, k, neg, ox, oa); }
 void ht_g2_op(int op, const uint32_t *acc, const uint32_t *q, const uint32_t *k, int neg, uint32_t *ox, uint32_t *oa) { point_op<Fq2>(op, acc, q, k, neg, ox, oa); }
 }
+
+// ---------------------------------------------------------------------------------------------- unsaturated (U-form) types
+template <class FS, class FU> static void fieldu_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *o) {
+    FU x = to_u(ld<FS>(a)), y = to_u(ld<FS>(b)), r;
+    switch (op) {
+        case 0: r = f_add(x, y); break;
+        case 1: r = f_sub(x, y); break;
+        case 2: r = f_mul(x, y); break;
+        case 3: r = f_sqr(x); break;
+        case 5: r = f_neg(x); break;
+        case 6: r = f_sub2(x, y); break;
+        case 7: {   // bound stress: a long un-reduced expression inside the documented limits
+            FU t = f_sub2(f_mul(x, y), f_sub(f_add(x, y), f_dbl(y)));      // < 2q + 64q
+            FU u = f_sub(f_sqr(t), f_add(f_mul(t, x), f_dbl(f_mul(t, y)))); // < 42q
+            r = f_sub(f_mul(t, f_sub2(x, u)), f_mul(u, y));
+            break;
+        }
+        default: r = x;
+    }
+    st(o, to_sat(r));
+}
+template <class FS, class FU> static XYZZ<FU> xyzz_to_u(const XYZZ<FS> &p) { return XYZZ<FU>{to_u(p.x), to_u(p.y), to_u(p.zz), to_u(p.zzz)}; }
+template <class FS, class FU> static XYZZ<FS> xyzz_to_sat(const XYZZ<FU> &p) { return XYZZ<FS>{to_sat(p.x), to_sat(p.y), to_sat(p.zz), to_sat(p.zzz)}; }
+template <class FS, class FU> static void pointu_op(int op, const uint32_t *acc_in, const uint32_t *q, int neg, int reps, uint32_t *out_aff) {
+    XYZZ<FU> acc = xyzz_to_u<FS, FU>(ld<XYZZ<FS>>(acc_in));
+    for (int i = 0; i < reps; i++) {
+        switch (op) {
+            case 0: { Affine<FS> s = ld<Affine<FS>>(q); Affine<FU> u{to_u(s.x), to_u(s.y)}; xyzz_madd(acc, u, neg != 0); break; }
+            case 1: { XYZZ<FU> u = xyzz_to_u<FS, FU>(ld<XYZZ<FS>>(q)); xyzz_add(acc, u); break; }
+            case 2: acc = xyzz_dbl(acc); break;
+        }
+    }
+    st(out_aff, xyzz_to_affine(xyzz_to_sat<FS, FU>(acc)));
+}
+extern "C" {
+void ht_fqu_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *o) { fieldu_op<Fq, FqU>(op, a, b, o); }
+void ht_fq2u_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *o) { fieldu_op<Fq2, Fq2U>(op, a, b, o); }
+int ht_fqu_is_zero_mod_k(int k, int delta) {   // is_zero_mod(k*q + delta) for the test
+    FqU x = FqU::zero();
+    unsigned long long carry = 0;
+    for (int i = 0; i < 14; i++) { unsigned long long v = (unsigned long long)k * FqUP::mod(i) + carry + (i == 0 ? (unsigned)delta : 0u); x.l[i] = (uint32_t)(v & FqU::MASK); carry = v >> 29; }
+    return fqu_is_zero_mod(x) ? 1 : 0;
+}
+void ht_g1u_op(int op, const uint32_t *acc, const uint32_t *q, int neg, int reps, uint32_t *oa) { pointu_op<Fq, FqU>(op, acc, q, neg, reps, oa); }
+void ht_g2u_op(int op, const uint32_t *acc, const uint32_t *q, int neg, int reps, uint32_t *oa) { pointu_op<Fq2, Fq2U>(op, acc, q, neg, reps, oa); }
+}

@@ -110,3 +110,84 @@ def test_curve_kat_host(shim, group):
         cx, _ = point_op(shim, group, 0, ax, q=ba, neg=1)
         _, back = point_op(shim, group, 0, cx, q=ba)
         assert np.array_equal(back, aa)
+
+
+# ---------------------------------------------------------------------------------------------- unsaturated 29-bit form
+def test_fqu_field_ops_vs_python(shim):
+    """csrc/ffu.cuh: saturated -> U-form -> op -> saturated equals the plain modular result."""
+    rng = random.Random(17)
+    q = P.Q_MOD
+    vals = [0, 1, 2, q - 1, q - 2, (1 << 380) % q] + [rng.randrange(q) for _ in range(120)]
+    for a in vals[:12]:
+        for b in vals[:12]:
+            for op, f in ((0, lambda x, y: x + y), (1, lambda x, y: x - y), (6, lambda x, y: x - y), (2, lambda x, y: x * y)):
+                got = P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", op, fq_mont(a), fq_mont(b))))
+                assert got == f(a, b) % q, (op, a, b)
+    for i in range(0, len(vals) - 1):
+        a, b = vals[i], vals[i + 1]
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 2, fq_mont(a), fq_mont(b)))) == a * b % q
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 3, fq_mont(a), fq_mont(b)))) == a * a % q
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 5, fq_mont(a), fq_mont(b)))) == (-a) % q
+        t = (a * b - ((a + b) - 2 * b)) % q
+        u = (t * t - (t * a + 2 * t * b)) % q
+        exp = (t * (a - u) - u * b) % q
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 7, fq_mont(a), fq_mont(b)))) == exp
+
+
+def test_fqu_is_zero_mod(shim):
+    for k in (0, 1, 2, 3, 7, 33, 63, 64, 74, 100, 127, 148, 1000, 4000):
+        assert shim.ht_fqu_is_zero_mod_k(k, 0) == 1, k
+        assert shim.ht_fqu_is_zero_mod_k(k, 1) == 0, k
+        assert shim.ht_fqu_is_zero_mod_k(k, 12345) == 0, k
+
+
+def test_fq2u_field_ops_vs_python(shim):
+    rng = random.Random(19)
+    enc = lambda p: np.concatenate([fq_mont(p.c0), fq_mont(p.c1)])
+    dec = lambda a: P.Fq2(P.fq_from_mont(unlimbs(a[:6])), P.fq_from_mont(unlimbs(a[6:])))
+    for _ in range(60):
+        a = P.Fq2(rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD))
+        b = P.Fq2(rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD))
+        assert dec(call_field(shim, "ht_fq2u_op", 2, enc(a), enc(b))) == a * b
+        assert dec(call_field(shim, "ht_fq2u_op", 3, enc(a), enc(b))) == a * a
+        assert dec(call_field(shim, "ht_fq2u_op", 1, enc(a), enc(b))) == a - b
+        t = a * b - ((a + b) - (b + b))
+        u = t * t - (t * a + (t * b + t * b))
+        assert dec(call_field(shim, "ht_fq2u_op", 7, enc(a), enc(b))) == t * (a - u) - u * b
+
+
+def pointu_op(shim, group, op, acc, q, neg=0, reps=1):
+    w = 12 if group == "g1" else 24
+    acc32, q32 = u32(acc), u32(q)
+    oa = np.zeros(2 * w, dtype=np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    getattr(shim, "ht_%su_op" % group)(op, p(acc32), p(q32), neg, reps, p(oa))
+    return oa.view(np.uint64)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_curve_kat_uform(shim, group):
+    """The XYZZ formulas instantiated over the unsaturated types (what the MSM kernels run) vs the golden vectors,
+    including the exceptional cases (P + P, P - P, infinity) and chains of un-reduced coordinates."""
+    kat = load("curve_kat.json")
+    w = 12 if group == "g1" else 24
+    gen = G1_GEN_LIMBS if group == "g1" else G2_GEN_LIMBS
+    enc = g1_limbs if group == "g1" else g2_limbs
+    inf_x = np.zeros(2 * w, dtype=np.uint64)
+    gen_x, _ = point_op(shim, group, 4, inf_x, q=gen)
+    for v in kat[group + "_add"]:
+        ax, aa = point_op(shim, group, 3, gen_x, k=fr_canon(H(v["a"])))      # saturated reference path
+        bx, ba = point_op(shim, group, 3, gen_x, k=fr_canon(H(v["b"])))
+        exp, _ = enc(v["p"])
+        assert np.array_equal(pointu_op(shim, group, 0, ax, ba), exp), v       # U-form mixed add
+        assert np.array_equal(pointu_op(shim, group, 1, ax, bx), exp), v       # U-form full add
+    # chains: acc = 5G; add G 40 times -> 45G; double 6 times -> 64*G*... vs python
+    ax, _ = point_op(shim, group, 3, gen_x, k=fr_canon(5))
+    mul = P.g1_mul if group == "g1" else P.g2_mul
+    py = py_g1 if group == "g1" else py_g2
+    assert np.array_equal(pointu_op(shim, group, 0, ax, gen, reps=40), py(mul(45))[0])
+    assert np.array_equal(pointu_op(shim, group, 0, ax, gen, neg=1, reps=3), py(mul(2))[0])
+    assert np.array_equal(pointu_op(shim, group, 0, ax, gen, neg=1, reps=5), np.zeros(w, dtype=np.uint64))     # 5G - 5G = inf
+    assert np.array_equal(pointu_op(shim, group, 0, ax, gen, neg=1, reps=7), py(mul(P.R_MOD - 2))[0])
+    assert np.array_equal(pointu_op(shim, group, 2, ax, gen, reps=9), py(mul(5 * 512))[0])
+    assert np.array_equal(pointu_op(shim, group, 1, ax, ax, reps=1), py(mul(10))[0])                          # add of equal points -> doubling branch

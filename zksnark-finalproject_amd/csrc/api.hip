@@ -95,27 +95,37 @@ void point_to_abi(const A &p, uint64_t *out, uint8_t *inf) {
     }
 }
 
-// Upload a slice [lo, hi) of an affine query vector into dst[0 .. hi-lo), zeroing flagged-infinity points.
+// Upload a slice [lo, hi) of a saturated affine query vector and convert it into the unsaturated device form at
+// dst[0 .. hi-lo); flagged-infinity points become (0,0).
+template <class A> struct UOf;
+template <> struct UOf<G1Affine> { using T = G1AffineU; };
+template <> struct UOf<G2Affine> { using T = G2AffineU; };
+inline void convert_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n) { convert_g1_bases(ctx, in, out, n); }
+inline void convert_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n) { convert_g2_bases(ctx, in, out, n); }
+
 template <class A>
-void upload_points(zkg16_ctx *ctx, A *dst, const uint64_t *src, const uint8_t *inf, size_t lo, size_t hi) {
+void upload_points(zkg16_ctx *ctx, typename UOf<A>::T *dst, const uint64_t *src, const uint8_t *inf, size_t lo, size_t hi) {
     if (hi <= lo) return;
     const size_t n = hi - lo;
     const A *s = reinterpret_cast<const A *>(src) + lo;
+    DevBuf stage(n * sizeof(A));
     if (!inf) {
-        ZK_HIP(hipMemcpyAsync(dst, s, n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
-        return;
+        ZK_HIP(hipMemcpyAsync(stage.p, s, n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        std::vector<A> tmp(s, s + n);
+        for (size_t i = 0; i < n; i++)
+            if (inf[lo + i]) tmp[i] = A::inf();
+        ZK_HIP(hipMemcpyAsync(stage.p, tmp.data(), n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));      // tmp is freed at scope exit
     }
-    std::vector<A> tmp(s, s + n);
-    for (size_t i = 0; i < n; i++)
-        if (inf[lo + i]) tmp[i] = A::inf();
-    ZK_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+    convert_bases(ctx, stage.as<A>(), dst, n);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
 
 template <class A>
-void upload_one(zkg16_ctx *ctx, A *dst, const A &p) {
-    ZK_HIP(hipMemcpyAsync(dst, &p, sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+void upload_one(zkg16_ctx *ctx, typename UOf<A>::T *dst, const A &p) {
+    const typename UOf<A>::T u{to_u(p.x), to_u(p.y)};     // host-side conversion (same templates)
+    ZK_HIP(hipMemcpyAsync(dst, &u, sizeof(u), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
 
@@ -179,15 +189,15 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
     ZK_HIP(hipEventRecord(ev[2], ctx->stream));
 
-    out.h = msm_g1_exec(ctx, ctx->ws_h, plan_h, pk.h.as<G1Affine>(), "H");
+    out.h = msm_g1_exec(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), "H");
     ZK_HIP(hipEventRecord(ev[3], ctx->stream));
-    out.l = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.l.as<G1Affine>(), "L");
+    out.l = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), "L");
     ZK_HIP(hipEventRecord(ev[4], ctx->stream));
-    out.a = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.a.as<G1Affine>(), "A");
+    out.a = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), "A");
     ZK_HIP(hipEventRecord(ev[5], ctx->stream));
-    out.b1 = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.b1.as<G1Affine>(), "B1");
+    out.b1 = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), "B1");
     ZK_HIP(hipEventRecord(ev[6], ctx->stream));
-    out.b2 = msm_g2_exec(ctx, ctx->ws_z, plan_z, pk.b2.as<G2Affine>(), "B2");
+    out.b2 = msm_g2_exec(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), "B2");
     ZK_HIP(hipEventRecord(ev[7], ctx->stream));
     ZK_HIP(hipEventSynchronize(ev[7]));
     float ms;
@@ -353,6 +363,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_window_bits = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "reduce_chunk")) {
+        if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_reduce_chunk = (int)value;
+        return ZKG16_OK;
+    }
     return ZKG16_ERR_UNSUPPORTED;
 }
 
@@ -382,25 +397,25 @@ int zkg16_pk_load(zkg16_ctx *ctx,
     pk->h_lo = n_h * (size_t)shard_index / shard_count;
     pk->h_hi = n_h * (size_t)(shard_index + 1) / shard_count;
     const size_t nz = pk->z_hi - pk->z_lo, nh = pk->h_hi - pk->h_lo;
-    pk->a.alloc((nz + 3) * sizeof(G1Affine));
-    pk->b1.alloc((nz + 3) * sizeof(G1Affine));
-    pk->l.alloc((nz + 3) * sizeof(G1Affine));
-    pk->b2.alloc((nz + 3) * sizeof(G2Affine));
-    pk->h.alloc((nh ? nh : 1) * sizeof(G1Affine));
+    pk->a.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->b1.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->l.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->b2.alloc((nz + 3) * sizeof(G2AffineU));
+    pk->h.alloc((nh ? nh : 1) * sizeof(G1AffineU));
     ZK_HIP(hipMemsetAsync(pk->a.p, 0, pk->a.bytes, ctx->stream));      // (0,0) = infinity everywhere by default
     ZK_HIP(hipMemsetAsync(pk->b1.p, 0, pk->b1.bytes, ctx->stream));
     ZK_HIP(hipMemsetAsync(pk->l.p, 0, pk->l.bytes, ctx->stream));
     ZK_HIP(hipMemsetAsync(pk->b2.p, 0, pk->b2.bytes, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    upload_points(ctx, pk->a.as<G1Affine>(), a_query, a_inf, pk->z_lo, pk->z_hi);
-    upload_points(ctx, pk->b1.as<G1Affine>(), b_g1_query, b_g1_inf, pk->z_lo, pk->z_hi);
-    upload_points(ctx, pk->b2.as<G2Affine>(), b_g2_query, b_g2_inf, pk->z_lo, pk->z_hi);
-    upload_points(ctx, pk->h.as<G1Affine>(), h_query, h_inf, pk->h_lo, pk->h_hi);
+    upload_points<G1Affine>(ctx, pk->a.as<G1AffineU>(), a_query, a_inf, pk->z_lo, pk->z_hi);
+    upload_points<G1Affine>(ctx, pk->b1.as<G1AffineU>(), b_g1_query, b_g1_inf, pk->z_lo, pk->z_hi);
+    upload_points<G2Affine>(ctx, pk->b2.as<G2AffineU>(), b_g2_query, b_g2_inf, pk->z_lo, pk->z_hi);
+    upload_points<G1Affine>(ctx, pk->h.as<G1AffineU>(), h_query, h_inf, pk->h_lo, pk->h_hi);
     // l_query[j] pairs with z[num_instance + j]: place it at the same index as its scalar in this shard's z slice
     {
         const size_t lo = pk->z_lo > num_instance ? pk->z_lo : num_instance, hi = pk->z_hi;
         if (hi > lo)
-            upload_points(ctx, pk->l.as<G1Affine>() + (lo - pk->z_lo), l_query, l_inf, lo - num_instance, hi - num_instance);
+            upload_points<G1Affine>(ctx, pk->l.as<G1AffineU>() + (lo - pk->z_lo), l_query, l_inf, lo - num_instance, hi - num_instance);
     }
     pk->alpha_g1 = g1_from_abi(alpha_g1, 0);
     pk->beta_g1 = g1_from_abi(beta_g1, 0);
@@ -408,10 +423,10 @@ int zkg16_pk_load(zkg16_ctx *ctx,
     pk->beta_g2 = g2_from_abi(beta_g2, 0);
     pk->delta_g2 = g2_from_abi(delta_g2, 0);
     // extra slots (scalars r, s, -rs):  a += r*delta1 ; b1 += s*delta1 ; b2 += s*delta2 ; l += (-rs)*delta1
-    upload_one(ctx, pk->a.as<G1Affine>() + nz + 0, pk->delta_g1);
-    upload_one(ctx, pk->b1.as<G1Affine>() + nz + 1, pk->delta_g1);
-    upload_one(ctx, pk->b2.as<G2Affine>() + nz + 1, pk->delta_g2);
-    upload_one(ctx, pk->l.as<G1Affine>() + nz + 2, pk->delta_g1);
+    upload_one<G1Affine>(ctx, pk->a.as<G1AffineU>() + nz + 0, pk->delta_g1);
+    upload_one<G1Affine>(ctx, pk->b1.as<G1AffineU>() + nz + 1, pk->delta_g1);
+    upload_one<G2Affine>(ctx, pk->b2.as<G2AffineU>() + nz + 1, pk->delta_g2);
+    upload_one<G1Affine>(ctx, pk->l.as<G1AffineU>() + nz + 2, pk->delta_g1);
     *pk_handle = ctx->next_handle++;
     ctx->pks[*pk_handle] = std::move(pk);
     ZK_API_END(ctx)
@@ -598,9 +613,9 @@ int msm_host_entry(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, co
     if ((!bases || !scalars) && n) return ZKG16_ERR_BAD_ARG;
     if (!out_affine) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    DevBuf d_bases((n ? n : 1) * sizeof(A)), d_sc((n ? n : 1) * sizeof(Fr));
+    DevBuf d_bases((n ? n : 1) * sizeof(typename UOf<A>::T)), d_sc((n ? n : 1) * sizeof(Fr));
     if (n) {
-        upload_points(ctx, d_bases.as<A>(), bases, inf, 0, n);
+        upload_points<A>(ctx, d_bases.as<typename UOf<A>::T>(), bases, inf, 0, n);
         ZK_HIP(hipMemcpyAsync(d_sc.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -610,8 +625,8 @@ int msm_host_entry(zkg16_ctx *ctx, const uint64_t *bases, const uint8_t *inf, co
         const double t0 = now_ms();
         MsmPlan plan;
         msm_plan_build(ctx, ctx->ws_h, d_sc.as<Fr>(), n, plan);
-        if constexpr (sizeof(A) == sizeof(G1Affine)) total = msm_g1_exec(ctx, ctx->ws_h, plan, d_bases.as<G1Affine>(), "msm");
-        else total = msm_g2_exec(ctx, ctx->ws_h, plan, d_bases.as<G2Affine>(), "msm");
+        if constexpr (sizeof(A) == sizeof(G1Affine)) total = msm_g1_exec(ctx, ctx->ws_h, plan, d_bases.as<G1AffineU>(), "msm");
+        else total = msm_g2_exec(ctx, ctx->ws_h, plan, d_bases.as<G2AffineU>(), "msm");
         ms_sum += now_ms() - t0;
     }
     if (ms_per_iter) *ms_per_iter = (float)(ms_sum / (iters < 1 ? 1 : iters));

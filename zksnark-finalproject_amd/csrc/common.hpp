@@ -72,9 +72,9 @@ struct PkDev {              // proving key shard resident in HBM (affine AoS; (0
     size_t num_instance = 0, m_total = 0;            // m_total = num_instance + num_witness (full key)
     size_t z_lo = 0, z_hi = 0;                       // index range of the a/b1/b2 (and padded l) queries kept here
     size_t h_lo = 0, h_hi = 0, n_h_total = 0;        // index range of h_query kept here
-    DevBuf a, b1, l;                                 // G1Affine[z_hi - z_lo + 3]  (three trailing slots: r, s, -rs terms)
-    DevBuf b2;                                       // G2Affine[z_hi - z_lo + 3]
-    DevBuf h;                                        // G1Affine[h_hi - h_lo]
+    DevBuf a, b1, l;                                 // G1AffineU[z_hi - z_lo + 3]  (three trailing slots: r, s, -rs terms)
+    DevBuf b2;                                       // G2AffineU[z_hi - z_lo + 3]
+    DevBuf h;                                        // G1AffineU[h_hi - h_lo]
     G1Affine a0, b1_0, alpha_g1, beta_g1, delta_g1;  // host copies for the tail
     G2Affine b2_0, beta_g2, delta_g2;
     int shard_index = 0, shard_count = 1;
@@ -113,6 +113,7 @@ struct zkg16_ctx {
     std::map<std::string, zk::KernelStat> kstats;
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
+    int opt_reduce_chunk = 0;
     int num_cus = 256;
 };
 
@@ -151,8 +152,11 @@ struct MsmPlan {
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
-G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1Affine *bases, const char *tag);
-G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2Affine *bases, const char *tag);
+G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, const char *tag);
+G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, const char *tag);
+// saturated (arkworks) affine points -> the unsaturated device form, on the ctx stream
+void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n);
+void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n);
 
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out);
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out);

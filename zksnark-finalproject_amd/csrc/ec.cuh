@@ -10,6 +10,7 @@
 // projective representation is free.
 #pragma once
 #include "ff.cuh"
+#include "ffu.cuh"
 
 namespace zk {
 
@@ -42,7 +43,7 @@ ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
     F M = f_add(f_dbl(X2), X2);
     XYZZ<F> r;
     r.x = f_sub(f_sqr(M), f_dbl(S));
-    r.y = f_sub(f_mul(M, f_sub(S, r.x)), f_mul(W, p.y));
+    r.y = f_sub(f_mul(M, f_sub2(S, r.x)), f_mul(W, p.y));
     r.zz = V;
     r.zzz = W;
     return r;
@@ -60,7 +61,7 @@ ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
     F M = f_add(f_dbl(X2), X2);
     XYZZ<F> r;
     r.x = f_sub(f_sqr(M), f_dbl(S));
-    r.y = f_sub(f_mul(M, f_sub(S, r.x)), f_mul(W, p.y));
+    r.y = f_sub(f_mul(M, f_sub2(S, r.x)), f_mul(W, p.y));
     r.zz = f_mul(V, p.zz);
     r.zzz = f_mul(W, p.zzz);
     return r;
@@ -78,18 +79,18 @@ ZK_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bool neg) {
     }
     F U2 = f_mul(q.x, acc.zz);
     F S2 = f_mul(q.y, acc.zzz);
-    F Pp = f_sub(U2, acc.x);
-    F R = f_sub(S2, acc.y);
-    if (Pp.is_zero()) {
-        if (R.is_zero()) acc = xyzz_dbl_affine(q);
+    F Pp = f_sub2(U2, acc.x);
+    F R = f_sub2(S2, acc.y);
+    if (f_is_zero_mod(Pp)) {
+        if (f_is_zero_mod(R)) acc = xyzz_dbl_affine(q);
         else acc = XYZZ<F>::inf();
         return;
     }
     F PP = f_sqr(Pp);
     F PPP = f_mul(Pp, PP);
     F Q = f_mul(acc.x, PP);
-    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-    acc.y = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(acc.y, PPP));
+    F X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    acc.y = f_sub(f_mul(R, f_sub2(Q, X3)), f_mul(acc.y, PPP));
     acc.x = X3;
     acc.zz = f_mul(acc.zz, PP);
     acc.zzz = f_mul(acc.zzz, PPP);
@@ -109,16 +110,16 @@ ZK_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
     F S2 = f_mul(q.y, acc.zzz);
     F Pp = f_sub(U2, U1);
     F R = f_sub(S2, S1);
-    if (Pp.is_zero()) {
-        if (R.is_zero()) acc = xyzz_dbl(acc);
+    if (f_is_zero_mod(Pp)) {
+        if (f_is_zero_mod(R)) acc = xyzz_dbl(acc);
         else acc = XYZZ<F>::inf();
         return;
     }
     F PP = f_sqr(Pp);
     F PPP = f_mul(Pp, PP);
     F Q = f_mul(U1, PP);
-    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-    acc.y = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(S1, PPP));
+    F X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    acc.y = f_sub(f_mul(R, f_sub2(Q, X3)), f_mul(S1, PPP));
     acc.x = X3;
     acc.zz = f_mul(f_mul(acc.zz, q.zz), PP);
     acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), PPP);
@@ -150,9 +151,14 @@ ZK_HD XYZZ<F> xyzz_mul(const XYZZ<F> &p, const uint32_t k[8]) {
     return acc;
 }
 
+// value-bound bookkeeping for the unsaturated types (ffu.cuh): products are < 2q (Fq) / < 10q per component (Fq2);
+// stored X, Y are one level-32 subtraction away from a product (< 42q); f_sub2 (level 64) is used wherever the
+// subtrahend is a stored coordinate.  For the saturated types f_sub2 == f_sub.
 using G1Affine = Affine<Fq>;
 using G2Affine = Affine<Fq2>;
 using G1XYZZ = XYZZ<Fq>;
 using G2XYZZ = XYZZ<Fq2>;
+using G1AffineU = Affine<FqU>;   // device-resident proving-key bases / bucket sums (unsaturated form)
+using G2AffineU = Affine<Fq2U>;
 
 }  // namespace zk

@@ -27,6 +27,7 @@ namespace zk {
 struct FrP {
     static constexpr int N = 8;
     static constexpr uint32_t INV = 0xffffffffu;  // -r^-1 mod 2^32
+    static constexpr uint64_t INV64 = 0xfffffffeffffffffull;
     ZK_HD static constexpr uint32_t mod(int i) {
         constexpr uint32_t M[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                    0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
@@ -47,6 +48,7 @@ struct FrP {
 struct FqP {
     static constexpr int N = 12;
     static constexpr uint32_t INV = 0xfffcfffdu;  // -q^-1 mod 2^32
+    static constexpr uint64_t INV64 = 0x89f3fffcfffcfffdull;
     ZK_HD static constexpr uint32_t mod(int i) {
         constexpr uint32_t M[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                     0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
@@ -221,6 +223,51 @@ ZK_HD Fp<P> fp_mul_inline(const Fp<P> &a, const Fp<P> &b) {
     return r;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host tail (window Horner, r/s scalar multiplications, normalisation): same values, 64-bit limbs + __int128
+// (the byte layout of 2k u32 limbs and k u64 limbs is identical on little-endian hosts).
+template <class P>
+inline Fp<P> fp_mul_host64(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int M = P::N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t A[M], B[M], MOD[M], t[M + 2];
+    for (int i = 0; i < M; i++) {
+        A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        MOD[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+    }
+    for (int i = 0; i < M + 2; i++) t[i] = 0;
+    for (int i = 0; i < M; i++) {
+        u128 c = 0;
+        for (int j = 0; j < M; j++) {
+            u128 x = (u128)A[j] * B[i] + t[j] + c;
+            t[j] = (uint64_t)x;
+            c = x >> 64;
+        }
+        u128 x = (u128)t[M] + c;
+        t[M] = (uint64_t)x;
+        t[M + 1] = (uint64_t)(x >> 64);
+        const uint64_t m = t[0] * P::INV64;
+        c = ((u128)m * MOD[0] + t[0]) >> 64;
+        for (int j = 1; j < M; j++) {
+            x = (u128)m * MOD[j] + t[j] + c;
+            t[j - 1] = (uint64_t)x;
+            c = x >> 64;
+        }
+        x = (u128)t[M] + c;
+        t[M - 1] = (uint64_t)x;
+        t[M] = t[M + 1] + (uint64_t)(x >> 64);
+    }
+    Fp<P> r;
+    for (int i = 0; i < M; i++) {
+        r.l[2 * i] = (uint32_t)t[i];
+        r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    fp_reduce_once(r);
+    return r;
+}
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device: the 12-limb product is a real function call (one copy of the ~1.4k-instruction body per code
 // object instead of one per use).  A point addition is 10-14 of these back to back; inlined, a single
@@ -247,7 +294,7 @@ ZK_HD Fp<P> fp_mul(const Fp<P> &a, const Fp<P> &b) {
         return fp_mul_inline(a, b);
     }
 #else
-    return fp_mul_inline(a, b);
+    return fp_mul_host64(a, b);
 #endif
 }
 

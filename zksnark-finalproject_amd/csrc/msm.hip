@@ -24,6 +24,12 @@
 
 namespace zk {
 
+template <class F> struct FieldTraits;
+template <> struct FieldTraits<FqU> { using Sat = Fq; static constexpr bool g2 = false; };
+template <> struct FieldTraits<Fq2U> { using Sat = Fq2; static constexpr bool g2 = true; };
+template <> struct FieldTraits<Fq> { using Sat = Fq; static constexpr bool g2 = false; };
+template <> struct FieldTraits<Fq2> { using Sat = Fq2; static constexpr bool g2 = true; };
+
 // ------------------------------------------------------------------------------------------------ vector ld/st
 template <class T>
 __device__ __forceinline__ T ldv(const T *p) {
@@ -248,46 +254,93 @@ __global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, const
 // only if it began earlier; if it begins at the segment start it is a TAIL (gb_start == start, gb_end > end).
 // Hence every spilled bucket has exactly one tail record followed by head records — what msm_fixup walks.
 
+// ---- weighted bucket reduction:  W = sum_b (b+1) B_b = sum_b SS_b,  SS_b = sum_{b' >= b} B_b'  (sum of suffix sums).
+// Depth matters more than work here (few thousand lanes, each a dependent chain of ~14-product additions), so the
+// running sum is cut into chunks of K buckets and the cross-chunk carry comes from a log-depth suffix scan:
+//   chunk_sums      S_c = sum of the chunk                                   (K-1 adds deep)
+//   scan_step x log incl_c = sum_{c' >= c} S_c'  (Hillis-Steele, ping-pong)   (1 add deep each)
+//   chunk_weighted  run = incl_{c+1}; for b in chunk, top down: run += B_b; acc += run     (2K adds deep)
+//   sum_step x log  W = sum_c acc_c  (pairwise halving)                     (1 add deep each)
 template <class F>
-struct ReduceArgs {
-    const XYZZ<F> *s_in, *t_in;   // [nwin][m]   (level 1: both = buckets)
-    XYZZ<F> *s_out, *t_out;       // [nwin][m/K]
-    size_t m;                     // blocks per window at this level
-    int k;                        // blocks combined per output
-    int log_block;                // log2(original buckets per input block)
-    int first;                    // level 1: t_in == s_in, skip the T sum
-    int nwin;
-};
+__global__ void __launch_bounds__(64) msm_chunk_sums_kernel(const XYZZ<F> *buckets, XYZZ<F> *sums, size_t nb, int k, int nwin) {
+    const size_t nchunks = nb / k;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nchunks * (size_t)nwin) return;
+    const size_t w = id / nchunks, c = id - w * nchunks;
+    const XYZZ<F> *p = buckets + w * nb + c * k;
+    XYZZ<F> acc = ldv(p);
+    for (int j = 1; j < k; j++) {
+        const XYZZ<F> q = ldv(p + j);
+        xyzz_add(acc, q);
+    }
+    stv(sums + id, acc);
+}
+
+// out[c] = in[c] + in[c + d]  (within a window of m entries; beyond the end: unchanged)
+template <class F>
+__global__ void __launch_bounds__(64) msm_scan_step_kernel(const XYZZ<F> *in, XYZZ<F> *out, size_t m, size_t d, int nwin) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= m * (size_t)nwin) return;
+    const size_t c = id % m;
+    XYZZ<F> x = ldv(in + id);
+    if (c + d < m) {
+        const XYZZ<F> y = ldv(in + id + d);
+        xyzz_add(x, y);
+    }
+    stv(out + id, x);
+}
 
 template <class F>
-__global__ void __launch_bounds__(64) msm_reduce_level_kernel(ReduceArgs<F> a) {
-    const size_t mo = a.m / a.k;
+__global__ void __launch_bounds__(64) msm_chunk_weighted_kernel(const XYZZ<F> *buckets, const XYZZ<F> *incl, XYZZ<F> *out, size_t nb, int k, int nwin) {
+    const size_t nchunks = nb / k;
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= mo * (size_t)a.nwin) return;
-    const size_t w = id / mo, d = id - w * mo;
-    const size_t base = w * a.m + d * a.k;
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf(), tsum = XYZZ<F>::inf();
-    for (int j = a.k - 1; j >= 1; j--) {
-        const XYZZ<F> sj = ldv(a.s_in + base + j);
-        xyzz_add(run, sj);
-        xyzz_add(acc, run);                       // acc = sum_j j * S_j
-        if (!a.first) {
-            const XYZZ<F> tj = ldv(a.t_in + base + j);
-            xyzz_add(tsum, tj);
-        }
+    if (id >= nchunks * (size_t)nwin) return;
+    const size_t w = id / nchunks, c = id - w * nchunks;
+    const XYZZ<F> *p = buckets + w * nb + c * k;
+    XYZZ<F> run = XYZZ<F>::inf();
+    if (c + 1 < nchunks) run = ldv(incl + id + 1);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int j = k - 1; j >= 0; j--) {
+        const XYZZ<F> q = ldv(p + j);
+        xyzz_add(run, q);
+        xyzz_add(acc, run);
     }
-    const XYZZ<F> s0 = ldv(a.s_in + base);
-    xyzz_add(run, s0);                            // run = sum_j S_j
-    if (a.first) {
-        xyzz_add(acc, run);                       // sum_j (j+1) P_j
-    } else {
-        const XYZZ<F> t0 = ldv(a.t_in + base);
-        xyzz_add(tsum, t0);
-        for (int q = 0; q < a.log_block; q++) acc = xyzz_dbl(acc);
-        xyzz_add(acc, tsum);
-    }
-    stv(a.s_out + w * mo + d, run);
-    stv(a.t_out + w * mo + d, acc);
+    stv(out + id, acc);
+}
+
+// buf[c] += buf[c + half] for c < half (within each window of `stride` entries)
+template <class F>
+__global__ void __launch_bounds__(64) msm_sum_step_kernel(XYZZ<F> *buf, size_t stride, size_t half, size_t live, int nwin) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= half * (size_t)nwin) return;
+    const size_t w = id / half, c = id - w * half;
+    if (c + half >= live) return;
+    XYZZ<F> x = ldv(buf + w * stride + c);
+    const XYZZ<F> y = ldv(buf + w * stride + c + half);
+    xyzz_add(x, y);
+    stv(buf + w * stride + c, x);
+}
+
+// ------------------------------------------------------------------------------------------------ representation changes
+// proving-key bases: arkworks saturated Montgomery -> unsaturated 29-bit form (ffu.cuh), once at pk-load time
+template <class FU>
+__global__ void __launch_bounds__(256) convert_bases_kernel(const Affine<typename FieldTraits<FU>::Sat> *in, Affine<FU> *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<typename FieldTraits<FU>::Sat> p = ldv(in + i);
+    Affine<FU> o{to_u(p.x), to_u(p.y)};      // (0,0) stays (0,0)
+    stv(out + i, o);
+}
+// window sums: entry w*stride of `in` -> saturated XYZZ for the host Horner
+template <class FU>
+__global__ void __launch_bounds__(64) convert_wsums_kernel(const XYZZ<FU> *in, size_t stride, XYZZ<typename FieldTraits<FU>::Sat> *out, int nwin) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    const XYZZ<FU> p = ldv(in + (size_t)w * stride);
+    XYZZ<typename FieldTraits<FU>::Sat> o;
+    if (p.is_inf()) o = XYZZ<typename FieldTraits<FU>::Sat>::inf();
+    else o = XYZZ<typename FieldTraits<FU>::Sat>{to_sat(p.x), to_sat(p.y), to_sat(p.zz), to_sat(p.zzz)};
+    stv(out + w, o);
 }
 
 // ------------------------------------------------------------------------------------------------ fixed base
@@ -377,8 +430,9 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 }
 
 template <class F>
-static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, const char *tag) {
-    if (plan.n == 0 || plan.total_entries == 0) return XYZZ<F>::inf();
+static XYZZ<typename FieldTraits<F>::Sat> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, const char *tag) {
+    using FS = typename FieldTraits<F>::Sat;
+    if (plan.n == 0 || plan.total_entries == 0) return XYZZ<FS>::inf();
     const size_t tb = plan.nb * plan.nwin;
     const size_t psz = sizeof(XYZZ<F>);
     ws.buckets.ensure(tb * psz);
@@ -400,7 +454,7 @@ static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     a.seg_len = plan.seg_len;
     const unsigned grid = (unsigned)((plan.nseg + 63) / 64);
     {
-        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_accumulate_g1" : "msm_accumulate_g2", (double)plan.total_entries);
+        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.total_entries);
         hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
     }
     {
@@ -408,7 +462,7 @@ static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
         uint32_t *long_list = ws.long_list.as<uint32_t>() + 1, *long_count = ws.long_list.as<uint32_t>();
         ZK_HIP(hipMemsetAsync(long_count, 0, sizeof(uint32_t), ctx->stream));
         {
-            ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_g1" : "msm_fixup_g2", (double)plan.nseg);
+            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)plan.nseg);
             hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a, long_list, long_count);
         }
         static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 384 B > the 64 KiB default for G2
@@ -417,45 +471,46 @@ static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
             lds_attr_set = true;
         }
         {
-            ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_fixup_long_g1" : "msm_fixup_long_g2", 0.0);
+            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0);
             hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, ctx->stream, a, long_list, long_count);
         }
     }
-    // weighted bucket reduction tree
-    const int kbits = 3;
-    size_t m = plan.nb;
-    int log_block = 0;
-    bool first = true;
-    const XYZZ<F> *s_in = a.buckets, *t_in = a.buckets;
-    DevBuf *bufs[4] = {&ws.lvl_a, &ws.lvl_b, &ws.lvl_c, &ws.lvl_d};
-    int flip = 0;
-    while (m > 1) {
-        const int k = m >= ((size_t)1 << kbits) ? (1 << kbits) : (int)m;
-        const size_t mo = m / k;
-        DevBuf *so = bufs[flip], *to = bufs[flip + 1];
-        so->ensure(mo * plan.nwin * psz);
-        to->ensure(mo * plan.nwin * psz);
-        ReduceArgs<F> r;
-        r.s_in = s_in; r.t_in = t_in;
-        r.s_out = so->as<XYZZ<F>>(); r.t_out = to->as<XYZZ<F>>();
-        r.m = m; r.k = k; r.log_block = log_block; r.first = first ? 1 : 0; r.nwin = plan.nwin;
-        const size_t threads = mo * plan.nwin;
-        ScopedKernelTimer kt(ctx, sizeof(F) == sizeof(Fq) ? "msm_reduce_level_g1" : "msm_reduce_level_g2", (double)(m * plan.nwin));
-        hipLaunchKernelGGL(msm_reduce_level_kernel<F>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream, r);
-        s_in = r.s_out; t_in = r.t_out;
-        int kb = 0;
-        while ((1 << kb) < k) kb++;
-        log_block += kb;
-        m = mo;
-        first = false;
-        flip ^= 2;
+    // weighted bucket reduction (see the kernels above)
+    const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
+    int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : 8;
+    while ((size_t)kk > plan.nb) kk >>= 1;
+    const size_t nchunks = plan.nb / kk;
+    const size_t tot = nchunks * plan.nwin;
+    ws.lvl_a.ensure(tot * psz);
+    ws.lvl_b.ensure(tot * psz);
+    ws.lvl_c.ensure(tot * psz);
+    XYZZ<F> *pa = ws.lvl_a.as<XYZZ<F>>(), *pb = ws.lvl_b.as<XYZZ<F>>(), *pc = ws.lvl_c.as<XYZZ<F>>();
+    const unsigned rgrid = (unsigned)((tot + 63) / 64);
+    {
+        ScopedKernelTimer kt(ctx, rname, (double)tb);
+        hipLaunchKernelGGL(msm_chunk_sums_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, a.buckets, pa, plan.nb, kk, plan.nwin);
+        XYZZ<F> *src = pa, *dst = pb;
+        for (size_t d = 1; d < nchunks; d <<= 1) {
+            hipLaunchKernelGGL(msm_scan_step_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, src, dst, nchunks, d, plan.nwin);
+            XYZZ<F> *t = src; src = dst; dst = t;
+        }
+        hipLaunchKernelGGL(msm_chunk_weighted_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, a.buckets, src, pc, plan.nb, kk, plan.nwin);
+        size_t live = nchunks;
+        while (live > 1) {
+            const size_t half = (live + 1) / 2;
+            hipLaunchKernelGGL(msm_sum_step_kernel<F>, dim3((unsigned)((half * plan.nwin + 63) / 64)), dim3(64), 0, ctx->stream, pc, nchunks, half, live, plan.nwin);
+            live = half;
+        }
     }
     ZK_HIP(hipGetLastError());
-    std::vector<XYZZ<F>> wsum(plan.nwin);
-    ZK_HIP(hipMemcpyAsync(wsum.data(), t_in, plan.nwin * psz, hipMemcpyDeviceToHost, ctx->stream));
+    ws.lvl_d.ensure(plan.nwin * sizeof(XYZZ<FS>));
+    hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, ctx->stream, pc, nchunks, ws.lvl_d.as<XYZZ<FS>>(), plan.nwin);
+    ZK_HIP(hipGetLastError());
+    std::vector<XYZZ<FS>> wsum(plan.nwin);
+    ZK_HIP(hipMemcpyAsync(wsum.data(), ws.lvl_d.p, plan.nwin * sizeof(XYZZ<FS>), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     // host Horner over windows: sum_w 2^(c*w) W_w
-    XYZZ<F> total = wsum[plan.nwin - 1];
+    XYZZ<FS> total = wsum[plan.nwin - 1];
     for (int w = plan.nwin - 2; w >= 0; w--) {
         for (int q = 0; q < plan.c; q++) total = xyzz_dbl(total);
         xyzz_add(total, wsum[w]);
@@ -464,11 +519,21 @@ static XYZZ<F> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     return total;
 }
 
-G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1Affine *bases, const char *tag) {
-    return msm_exec<Fq>(ctx, ws, plan, bases, tag);
+G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, const char *tag) {
+    return msm_exec<FqU>(ctx, ws, plan, bases, tag);
 }
-G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2Affine *bases, const char *tag) {
-    return msm_exec<Fq2>(ctx, ws, plan, bases, tag);
+G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, const char *tag) {
+    return msm_exec<Fq2U>(ctx, ws, plan, bases, tag);
+}
+void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(convert_bases_kernel<FqU>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, out, n);
+    ZK_HIP(hipGetLastError());
+}
+void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(convert_bases_kernel<Fq2U>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, out, n);
+    ZK_HIP(hipGetLastError());
 }
 
 template <class F>
