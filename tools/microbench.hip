@@ -3,8 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <vector>
-#include "../zksnark-finalproject_amd/csrc/ff.cuh"
+#include "../zksnark-finalproject_amd/csrc/ec.cuh"
 using namespace zk;
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -101,9 +102,75 @@ __global__ void __launch_bounds__(256) k_fr_mul(uint32_t *out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
 }
 
+// unsaturated 29-bit product variants
+template <int NACC>
+__device__ __forceinline__ FqU fqu_mul_var(const FqU &a, const FqU &b) {
+    constexpr int N = 14;
+    uint32_t m[N];
+    FqU r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+        const int lo = k < N ? 0 : k - N + 1;
+        const int hi = k < N ? k : N - 1;
+        uint64_t acc[4] = {carry, 0, 0, 0};
+        int t = 0;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) { acc[t % NACC] += (uint64_t)a.l[i] * b.l[k - i]; t++; }
+        if (k < N) {
+#pragma unroll
+            for (int i = 0; i < k; i++) { acc[t % NACC] += (uint64_t)m[i] * FqUP::mod(k - i); t++; }
+            uint64_t s = acc[0];
+#pragma unroll
+            for (int j = 1; j < NACC; j++) s += acc[j];
+            m[k] = ((uint32_t)s * FqUP::INV) & FqU::MASK;
+            s += (uint64_t)m[k] * FqUP::mod(0);
+            carry = s >> 29;
+        } else {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) { acc[t % NACC] += (uint64_t)m[i] * FqUP::mod(k - i); t++; }
+            uint64_t s = acc[0];
+#pragma unroll
+            for (int j = 1; j < NACC; j++) s += acc[j];
+            r.l[k - N] = (uint32_t)s & FqU::MASK;
+            carry = s >> 29;
+        }
+    }
+    r.l[N - 1] = (uint32_t)carry;
+    return r;
+}
+template <int NACC>
+__global__ void __launch_bounds__(256) k_fqu_mul_var(uint32_t *out, uint32_t seed) {
+    FqU a = FqU::one(), b = FqU::one();
+    a.l[0] += threadIdx.x & 0xff; b.l[1] ^= seed & 0xfff;
+    for (int it = 0; it < ITERS / 16; it++) { a = fqu_mul_var<NACC>(a, b); b = fqu_mul_var<NACC>(b, a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
+}
+__global__ void __launch_bounds__(256) k_fqu_mul_call(uint32_t *out, uint32_t seed) {
+    FqU a = FqU::one(), b = FqU::one();
+    a.l[0] += threadIdx.x & 0xff; b.l[1] ^= seed & 0xfff;
+    for (int it = 0; it < ITERS / 16; it++) { a = fqu_mul(a, b); b = fqu_mul(b, a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0] ^ b.l[3];
+}
+__global__ void __launch_bounds__(256) k_fqu_sqr_call(uint32_t *out, uint32_t seed) {
+    FqU a = FqU::one();
+    a.l[0] += threadIdx.x & 0xff; a.l[1] ^= seed & 0xfff;
+    for (int it = 0; it < ITERS / 8; it++) { a = fqu_sqr(a); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a.l[0];
+}
+// one XYZZ mixed addition per iteration (the accumulate kernel's inner body), G1 and G2
+template <class F>
+__global__ void __launch_bounds__(64) k_madd(uint32_t *out, uint32_t seed) {
+    XYZZ<F> acc = XYZZ<F>{F::one(), F::one(), F::one(), F::one()};
+    Affine<F> q{F::one(), F::one()};
+    for (int it = 0; it < ITERS / 64; it++) { xyzz_madd(acc, q, (it & 1) != 0); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = ((uint32_t *)&acc)[0] ^ seed;
+}
+
 template <class K>
 static int run(const char *name, K kernel, double ops_per_thread, int blocks_per_cu, uint32_t *d_out) {
-    const int cus = 256, threads = 256;
+    const int cus = 256;
+    const int threads = strstr(name, "64thr") ? 64 : 256;
     const int grid = cus * blocks_per_cu;
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -146,6 +213,17 @@ int main() {
         run("v_fma_f64", k_fma_f64, per, b, d_out);
     }
     const double muls = 2.0 * (ITERS / 16);
+    for (int b : {1, 2, 4}) {
+        run("FqU mul (call)", k_fqu_mul_call, muls, b, d_out);
+        run("FqU sqr (call)", k_fqu_sqr_call, (double)(ITERS / 8), b, d_out);
+        run("FqU mul inline 1acc", k_fqu_mul_var<1>, muls, b, d_out);
+        run("FqU mul inline 2acc", k_fqu_mul_var<2>, muls, b, d_out);
+        run("FqU mul inline 4acc", k_fqu_mul_var<4>, muls, b, d_out);
+    }
+    for (int b : {4, 8, 16}) {   // 64-thread blocks: b blocks/CU = b/4 waves per SIMD
+        run("madd G1 (64thr blk)", k_madd<FqU>, (double)(ITERS / 64), b, d_out);
+        run("madd G2 (64thr blk)", k_madd<Fq2U>, (double)(ITERS / 64), b, d_out);
+    }
     for (int b : {1, 2, 4, 8}) {
         run("Fq mul (call)", k_fq_mul, muls, b, d_out);
         run("Fq mul (inline)", k_fq_mul_inline, muls, b, d_out);

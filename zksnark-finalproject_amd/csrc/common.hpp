@@ -90,7 +90,7 @@ struct R1csDev {
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list;
+    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list, tile_sums;
 };
 
 }  // namespace zk

@@ -102,32 +102,82 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars
     }
 }
 
-// exclusive scan of counts[0..total) -> offsets[0..total]; single workgroup, LDS tree over per-thread partials
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *counts, uint32_t *offsets, size_t total) {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
-    const size_t per = (total + 1023) / 1024;
-    const size_t lo = (size_t)tid * per, hi = lo + per < total ? lo + per : total;
-    uint32_t sum = 0;
-    for (size_t k = lo; k < hi; k++) sum += counts[k];
-    part[tid] = sum;
+// exclusive scan of counts[0..total) -> offsets[0..total] in three coalesced steps:
+//   tile sums (4096 entries per workgroup) -> scan of the tile sums (one workgroup) -> per-tile scan + tile offset
+static constexpr int SCAN_TILE = 4096;      // 256 threads x 16 entries
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *sh, uint32_t *total) {
+    // wave-level inclusive scan by shuffles, then a 4-entry LDS combine
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) sh[wave] = x;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {       // Hillis-Steele inclusive scan
-        uint32_t v = tid >= d ? part[tid - d] : 0;
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += sh[w];
+    if (total) *total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(256) msm_scan_tile_sums_kernel(const uint32_t *counts, uint32_t *tile_sums, size_t total) {
+    __shared__ uint32_t sh[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < total) sum += counts[i];
+    }
+    uint32_t tot;
+    (void)block_exclusive_scan_256(sum, sh, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of up to 256*16 tile sums in place; writes the grand total to *grand
+__global__ void __launch_bounds__(256) msm_scan_tiles_kernel(uint32_t *tile_sums, size_t ntiles, uint32_t *grand) {
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (size_t base = 0; base < ntiles; base += 256) {
+        const size_t i = base + threadIdx.x;
+        const uint32_t v = i < ntiles ? tile_sums[i] : 0;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan_256(v, sh, &tot);
+        const uint32_t carry = carry_sh;
+        if (i < ntiles) tile_sums[i] = carry + ex;
         __syncthreads();
-        part[tid] += v;
+        if (threadIdx.x == 0) carry_sh = carry + tot;
         __syncthreads();
     }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (size_t k = lo; k < hi; k++) {
-        offsets[k] = run;
-        run += counts[k];
+    if (threadIdx.x == 0) *grand = carry_sh;
+}
+
+__global__ void __launch_bounds__(256) msm_scan_apply_kernel(const uint32_t *counts, const uint32_t *tile_offsets, uint32_t *offsets, size_t total) {
+    __shared__ uint32_t sh[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;   // 16 consecutive entries per thread
+    uint32_t v[16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v[k] = base + k < total ? counts[base + k] : 0;
+        sum += v[k];
     }
-    if (tid == 1023) offsets[total] = part[1023];
+    uint32_t run = tile_offsets[blockIdx.x] + block_exclusive_scan_256(sum, sh, nullptr);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (base + k < total) offsets[base + k] = run;
+        run += v[k];
+    }
 }
 
 __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *keys, size_t n, int nwin, size_t nb,
-                                                          const uint32_t *offsets, uint32_t *cursors, uint32_t *entries) {
+                                                          const uint32_t *offsets, uint32_t *cursors, uint2 *entries) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * (size_t)nwin) return;
     const uint32_t key = keys[idx];
@@ -135,60 +185,68 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *keys, 
     const size_t w = idx / n, i = idx - w * n;
     const size_t g = w * nb + ((key - 1u) >> 1);
     const uint32_t pos = offsets[g] + atomicAdd(&cursors[g], 1u);
-    entries[pos] = ((uint32_t)i << 1) | ((key - 1u) & 1u);
+    // (base index, sign) and the bucket id travel together: the accumulation loop never touches the offset table
+    entries[pos] = make_uint2(((uint32_t)i << 1) | ((key - 1u) & 1u), (uint32_t)g);
 }
 
 // ------------------------------------------------------------------------------------------------ base side
 template <class F>
 struct AccArgs {
     const Affine<F> *bases;
-    const uint32_t *entries, *offsets;
+    const uint2 *entries;        // .x = base index << 1 | negate, .y = global bucket id (window * 2^(c-1) + bucket)
+    const uint32_t *offsets;
     XYZZ<F> *buckets, *seg_head, *seg_tail;
     int32_t *seg_meta;          // [2*t] = bucket of head partial or -1, [2*t+1] = bucket of tail partial or -1
     size_t total_entries, total_buckets, nseg;
     int seg_len;
 };
 
+// G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
 template <class F>
-__global__ void __launch_bounds__(64) msm_accumulate_kernel(AccArgs<F> a) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate_kernel(AccArgs<F> a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.nseg) return;
-    const size_t start = t * (size_t)a.seg_len;
-    const size_t end = start + a.seg_len < a.total_entries ? start + a.seg_len : a.total_entries;
-    // bucket containing `start`: largest g with offsets[g] <= start (and offsets[g+1] > start)
-    size_t lo = 0, hi = a.total_buckets;          // invariant: offsets[lo] <= start < offsets[hi]
-    while (hi - lo > 1) {
-        const size_t mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= start) lo = mid; else hi = mid;
-    }
-    size_t g = lo;
-    uint32_t g_end = a.offsets[g + 1];
+    const uint32_t total = (uint32_t)a.total_entries;
+    const uint32_t start = t * (uint32_t)a.seg_len;
+    const uint32_t end = start + a.seg_len < total ? start + a.seg_len : total;
+    uint2 en = a.entries[start];
+    const uint32_t g_first = en.y;
+    const bool head_open = start > 0 && a.entries[start - 1].y == g_first;   // first bucket began in an earlier segment
+    const uint32_t g_after = end < total ? a.entries[end].y : 0xffffffffu;   // bucket that continues into the next segment
     int32_t head_b = -1, tail_b = -1;
     XYZZ<F> acc = XYZZ<F>::inf();
-    auto flush = [&](size_t gb, uint32_t gb_end) {
-        const uint32_t gb_start = a.offsets[gb];
-        if (gb_start < start) {                   // began in an earlier segment
-            head_b = (int32_t)gb;
-            stv(a.seg_head + t, acc);
-        } else if (gb_end > end) {                // continues into the next segment
-            tail_b = (int32_t)gb;
-            stv(a.seg_tail + t, acc);
-        } else if (!acc.is_inf()) {
-            stv(a.buckets + gb, acc);             // complete (buckets[] is pre-zeroed = infinity)
+    uint32_t cur = g_first;
+    uint32_t e = en.x, gb = en.y;
+    for (uint32_t p = start; p < end; p++) {
+        // next entry's index words are fetched a full mixed addition ahead of their use
+        if (p + 1 < end) en = a.entries[p + 1];
+        const uint32_t e_n = en.x, g_n = en.y;
+        if (gb != cur) {
+            // a bucket that began in an earlier segment is this segment's HEAD partial; one that continues into the
+            // next is its TAIL partial (a bucket doing both is recorded as head only); everything else is complete.
+            if (cur == g_first && head_open) {
+                head_b = (int32_t)cur;
+                stv(a.seg_head + t, acc);
+            } else if (!acc.is_inf()) {
+                stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+            }
+            acc = XYZZ<F>::inf();
+            cur = gb;
         }
-        acc = XYZZ<F>::inf();
-    };
-    for (size_t p = start; p < end; p++) {
-        while (p >= g_end) {
-            if (a.offsets[g] < g_end) flush(g, g_end);    // skip empty buckets
-            g++;
-            g_end = a.offsets[g + 1];
-        }
-        const uint32_t e = a.entries[p];
         const Affine<F> b = ldv(a.bases + (e >> 1));
         xyzz_madd(acc, b, (e & 1u) != 0);
+        e = e_n;
+        gb = g_n;
     }
-    if (end > start) flush(g, g_end);
+    if (cur == g_first && head_open) {
+        head_b = (int32_t)cur;
+        stv(a.seg_head + t, acc);
+    } else if (cur == g_after) {
+        tail_b = (int32_t)cur;
+        stv(a.seg_tail + t, acc);
+    } else if (!acc.is_inf()) {
+        stv(a.buckets + cur, acc);
+    }
     a.seg_meta[2 * t] = head_b;
     a.seg_meta[2 * t + 1] = tail_b;
 }
@@ -398,7 +456,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
     ws.keys.ensure(n * plan.nwin * sizeof(uint32_t));
-    ws.entries.ensure(n * plan.nwin * sizeof(uint32_t));
+    ws.entries.ensure(n * plan.nwin * sizeof(uint2));
     ws.counts.ensure(tb * sizeof(uint32_t));
     ws.cursors.ensure(tb * sizeof(uint32_t));
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
@@ -411,15 +469,21 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
                            ws.keys.as<uint32_t>(), ws.counts.as<uint32_t>());
     }
     {
+        const size_t ntiles = (tb + SCAN_TILE - 1) / SCAN_TILE;
+        ws.tile_sums.ensure((ntiles + 1) * sizeof(uint32_t));
+        uint32_t *tiles = ws.tile_sums.as<uint32_t>();
         ScopedKernelTimer kt(ctx, "msm_scan_kernel", (double)tb);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ws.counts.as<uint32_t>(), ws.offsets.as<uint32_t>(), tb);
+        hipLaunchKernelGGL(msm_scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles, tb);
+        hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, tiles, ntiles, ws.offsets.as<uint32_t>() + tb);
+        hipLaunchKernelGGL(msm_scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles,
+                           ws.offsets.as<uint32_t>(), tb);
     }
     {
         const size_t tot = n * (size_t)plan.nwin;
         ScopedKernelTimer kt(ctx, "msm_scatter_kernel", (double)tot);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
                            ws.keys.as<uint32_t>(), n, plan.nwin, plan.nb, ws.offsets.as<uint32_t>(), ws.cursors.as<uint32_t>(),
-                           ws.entries.as<uint32_t>());
+                           ws.entries.as<uint2>());
     }
     ZK_HIP(hipGetLastError());
     uint32_t total = 0;
@@ -442,7 +506,7 @@ static XYZZ<typename FieldTraits<F>::Sat> msm_exec(zkg16_ctx *ctx, MsmWorkspace 
     ZK_HIP(hipMemsetAsync(ws.buckets.p, 0, tb * psz, ctx->stream));
     AccArgs<F> a;
     a.bases = bases;
-    a.entries = ws.entries.as<uint32_t>();
+    a.entries = ws.entries.as<uint2>();
     a.offsets = ws.offsets.as<uint32_t>();
     a.buckets = ws.buckets.as<XYZZ<F>>();
     a.seg_head = ws.seg_head.as<XYZZ<F>>();
