@@ -11,20 +11,22 @@
 using namespace zk;
 
 namespace zk {
-ScopedKernelTimer::ScopedKernelTimer(zkg16_ctx *c, const char *n, double u) : ctx(c), name(n), units(u) {
+ScopedKernelTimer::ScopedKernelTimer(zkg16_ctx *c, const char *n, double u, hipStream_t st)
+    : ctx(c), name(n), units(u), stream(st ? st : c->stream) {
     if (!ctx->kernel_timing) return;
     ZK_HIP(hipEventCreate(&e0));
     ZK_HIP(hipEventCreate(&e1));
-    ZK_HIP(hipEventRecord(e0, ctx->stream));
+    ZK_HIP(hipEventRecord(e0, stream));
 }
 ScopedKernelTimer::~ScopedKernelTimer() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, stream);
     ctx->pending_events.push_back(PendingEvent{name, units, e0, e1});
 }
 void kernel_timer_resolve(zkg16_ctx *ctx) {
     if (ctx->pending_events.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
     for (auto &p : ctx->pending_events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -189,21 +191,26 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
     ZK_HIP(hipEventRecord(ev[2], ctx->stream));
 
-    out.h = msm_g1_exec(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), "H");
-    ZK_HIP(hipEventRecord(ev[3], ctx->stream));
-    out.l = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), "L");
-    ZK_HIP(hipEventRecord(ev[4], ctx->stream));
-    out.a = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), "A");
-    ZK_HIP(hipEventRecord(ev[5], ctx->stream));
-    out.b1 = msm_g1_exec(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), "B1");
-    ZK_HIP(hipEventRecord(ev[6], ctx->stream));
-    out.b2 = msm_g2_exec(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), "B2");
-    ZK_HIP(hipEventRecord(ev[7], ctx->stream));
-    ZK_HIP(hipEventSynchronize(ev[7]));
+    // queue all five MSMs (the G2 one first: its long reduction then hides behind the four G1 accumulations), then
+    // collect: each MSM's host Horner overlaps the device work still queued behind it
+    msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+    msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
+    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
+    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
+    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    double tprev = now_ms();
+    auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
+    out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
+    out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
+    out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
+    out.a = msm_g1_collect(ctx, ctx->slots[3]); lap(5);
+    out.b1 = msm_g1_collect(ctx, ctx->slots[4]); lap(6);
+    ZK_HIP(hipEventSynchronize(ev[2]));
     float ms;
-    // [0] spmv (reported inside [1] for now), [1] witness map, [2] digits+sort, [3..7] MSMs
+    // [1] witness map, [2] digits+sort (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2 (collected in
+    // the order B2, H, L, A, B1 — the first gap contains most of the device time)
     ctx->timings[0] = 0;
-    for (int i = 1; i <= 7; i++) {
+    for (int i = 1; i <= 2; i++) {
         ZK_HIP(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
         ctx->timings[i] = ms;
     }
@@ -334,6 +341,7 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
         ZK_HIP(hipGetDeviceProperties(&prop, dev));
         ctx->num_cus = prop.multiProcessorCount;
         ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     } catch (const HipError &e) {
         int rc = fail(ctx, e);
         delete ctx;
@@ -347,10 +355,20 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    for (auto &sl : ctx->slots) {
+        if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
+        if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
+        if (sl.red_done) (void)hipEventDestroy(sl.red_done);
+        sl.buckets.release();
+        sl.wsums_dev.release();
+    }
+    ctx->red_a.release(); ctx->red_b.release(); ctx->red_c.release();
     ctx->pks.clear();
     ctx->r1cs.clear();
     ctx->wits.clear();
     ctx->ntt_tables.clear();
+    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

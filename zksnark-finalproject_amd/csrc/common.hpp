@@ -89,6 +89,15 @@ struct R1csDev {
 
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
+struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
+    DevBuf buckets, wsums_dev;
+    void *wsums_host = nullptr;   // pinned
+    size_t host_bytes = 0;
+    hipEvent_t acc_done = nullptr, red_done = nullptr;
+    int nwin = 0, c = 0;
+    bool active = false;
+};
+
 struct MsmWorkspace {       // grown on demand, reused across proofs
     DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list, tile_sums;
 };
@@ -106,6 +115,9 @@ struct zkg16_ctx {
     std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
     uint64_t next_handle = 1;
     zk::MsmWorkspace ws_z, ws_h;                      // one workspace per scalar vector (z-side, h-side)
+    hipStream_t aux_stream = nullptr;                 // bucket reductions run here, overlapping the next accumulation
+    zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
+    zk::DevBuf red_a, red_b, red_c;                   // reduction scratch (aux stream is in-order, so shared)
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
     zk::DevBuf hscal;                                 // canonical h
     float timings[16] = {0};
@@ -128,7 +140,8 @@ struct ScopedKernelTimer {
     const char *name;
     double units;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ScopedKernelTimer(zkg16_ctx *c, const char *n, double u);
+    hipStream_t stream;
+    ScopedKernelTimer(zkg16_ctx *c, const char *n, double u, hipStream_t st = nullptr);
     ~ScopedKernelTimer();
 };
 void kernel_timer_resolve(zkg16_ctx *ctx);
@@ -152,6 +165,10 @@ struct MsmPlan {
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
+void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
+void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);
+G1XYZZ msm_g1_collect(zkg16_ctx *ctx, MsmSlot &slot);
+G2XYZZ msm_g2_collect(zkg16_ctx *ctx, MsmSlot &slot);
 G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, const char *tag);
 G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, const char *tag);
 // saturated (arkworks) affine points -> the unsaturated device form, on the ctx stream

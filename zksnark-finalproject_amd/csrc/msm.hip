@@ -197,7 +197,8 @@ struct AccArgs {
     const uint32_t *offsets;
     XYZZ<F> *buckets, *seg_head, *seg_tail;
     int32_t *seg_meta;          // [2*t] = bucket of head partial or -1, [2*t+1] = bucket of tail partial or -1
-    size_t total_entries, total_buckets, nseg;
+    const uint32_t *total_ptr;  // number of sorted entries (= offsets[total_buckets]); read on the device, no host sync
+    size_t total_buckets;
     int seg_len;
 };
 
@@ -205,9 +206,9 @@ struct AccArgs {
 template <class F>
 __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate_kernel(AccArgs<F> a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.nseg) return;
-    const uint32_t total = (uint32_t)a.total_entries;
+    const uint32_t total = *a.total_ptr;
     const uint32_t start = t * (uint32_t)a.seg_len;
+    if (start >= total) return;
     const uint32_t end = start + a.seg_len < total ? start + a.seg_len : total;
     uint2 en = a.entries[start];
     const uint32_t g_first = en.y;
@@ -259,7 +260,7 @@ static constexpr int FIXUP_SHORT = 4;
 template <class F>
 __global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *long_list, uint32_t *long_count) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.nseg) return;
+    if (t * (size_t)a.seg_len >= (size_t)*a.total_ptr) return;
     const int32_t g = a.seg_meta[2 * t + 1];
     if (g < 0) return;
     const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)a.seg_len;   // segment holding the bucket's last term
@@ -463,7 +464,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     ZK_HIP(hipMemsetAsync(ws.counts.p, 0, tb * sizeof(uint32_t), ctx->stream));
     ZK_HIP(hipMemsetAsync(ws.cursors.p, 0, tb * sizeof(uint32_t), ctx->stream));
     {
-        ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n);
+        ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const uint32_t *>(scalars_canonical), n, plan.c, plan.nwin, plan.nb,
                            ws.keys.as<uint32_t>(), ws.counts.as<uint32_t>());
@@ -472,7 +473,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
         const size_t ntiles = (tb + SCAN_TILE - 1) / SCAN_TILE;
         ws.tile_sums.ensure((ntiles + 1) * sizeof(uint32_t));
         uint32_t *tiles = ws.tile_sums.as<uint32_t>();
-        ScopedKernelTimer kt(ctx, "msm_scan_kernel", (double)tb);
+        ScopedKernelTimer kt(ctx, "msm_scan_kernel", (double)tb, ctx->stream);
         hipLaunchKernelGGL(msm_scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles, tb);
         hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, tiles, ntiles, ws.offsets.as<uint32_t>() + tb);
         hipLaunchKernelGGL(msm_scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles,
@@ -480,45 +481,54 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     }
     {
         const size_t tot = n * (size_t)plan.nwin;
-        ScopedKernelTimer kt(ctx, "msm_scatter_kernel", (double)tot);
+        ScopedKernelTimer kt(ctx, "msm_scatter_kernel", (double)tot, ctx->stream);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
                            ws.keys.as<uint32_t>(), n, plan.nwin, plan.nb, ws.offsets.as<uint32_t>(), ws.cursors.as<uint32_t>(),
                            ws.entries.as<uint2>());
     }
     ZK_HIP(hipGetLastError());
-    uint32_t total = 0;
-    ZK_HIP(hipMemcpyAsync(&total, ws.offsets.as<uint32_t>() + tb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    plan.total_entries = total;
-    plan.nseg = (total + plan.seg_len - 1) / plan.seg_len;
+    // the exact entry count stays on the device (offsets[tb]); launches are sized by the bound n * windows
+    plan.total_entries = n * (size_t)plan.nwin;
+    plan.nseg = (plan.total_entries + plan.seg_len - 1) / plan.seg_len;
 }
 
+// An MSM runs in two halves on two HIP streams so that the latency-bound bucket reduction of one MSM overlaps the
+// throughput-bound bucket accumulation of the next:
+//   main stream: clear buckets -> accumulate -> fix-ups                      -> event acc_done
+//   aux  stream: wait acc_done -> reduction -> convert window sums -> D2H   -> event red_done
+//   host       : wait red_done -> Horner over the window sums (msm_collect)
 template <class F>
-static XYZZ<typename FieldTraits<F>::Sat> msm_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, const char *tag) {
+static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot) {
     using FS = typename FieldTraits<F>::Sat;
-    if (plan.n == 0 || plan.total_entries == 0) return XYZZ<FS>::inf();
+    slot.active = false;
+    slot.nwin = plan.nwin;
+    slot.c = plan.c;
+    if (plan.n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
     const size_t psz = sizeof(XYZZ<F>);
-    ws.buckets.ensure(tb * psz);
+    if (!slot.acc_done) {
+        ZK_HIP(hipEventCreateWithFlags(&slot.acc_done, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&slot.red_done, hipEventDisableTiming));
+    }
+    slot.buckets.ensure(tb * psz);
     ws.seg_head.ensure(plan.nseg * psz);
     ws.seg_tail.ensure(plan.nseg * psz);
     ws.seg_meta.ensure(plan.nseg * 2 * sizeof(int32_t));
-    ZK_HIP(hipMemsetAsync(ws.buckets.p, 0, tb * psz, ctx->stream));
+    ZK_HIP(hipMemsetAsync(slot.buckets.p, 0, tb * psz, ctx->stream));
     AccArgs<F> a;
     a.bases = bases;
     a.entries = ws.entries.as<uint2>();
     a.offsets = ws.offsets.as<uint32_t>();
-    a.buckets = ws.buckets.as<XYZZ<F>>();
+    a.buckets = slot.buckets.as<XYZZ<F>>();
     a.seg_head = ws.seg_head.as<XYZZ<F>>();
     a.seg_tail = ws.seg_tail.as<XYZZ<F>>();
     a.seg_meta = ws.seg_meta.as<int32_t>();
-    a.total_entries = plan.total_entries;
+    a.total_ptr = ws.offsets.as<uint32_t>() + tb;
     a.total_buckets = tb;
-    a.nseg = plan.nseg;
     a.seg_len = plan.seg_len;
     const unsigned grid = (unsigned)((plan.nseg + 63) / 64);
     {
-        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.total_entries);
+        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
         hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
     }
     {
@@ -526,68 +536,94 @@ static XYZZ<typename FieldTraits<F>::Sat> msm_exec(zkg16_ctx *ctx, MsmWorkspace 
         uint32_t *long_list = ws.long_list.as<uint32_t>() + 1, *long_count = ws.long_list.as<uint32_t>();
         ZK_HIP(hipMemsetAsync(long_count, 0, sizeof(uint32_t), ctx->stream));
         {
-            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)plan.nseg);
+            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)plan.nseg, ctx->stream);
             hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a, long_list, long_count);
         }
-        static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 384 B > the 64 KiB default for G2
+        static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
         if (!lds_attr_set) {
             ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             lds_attr_set = true;
         }
         {
-            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0);
+            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0, ctx->stream);
             hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, ctx->stream, a, long_list, long_count);
         }
     }
-    // weighted bucket reduction (see the kernels above)
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipEventRecord(slot.acc_done, ctx->stream));
+
+    // ---- aux stream: weighted bucket reduction (see the kernels above)
+    hipStream_t aux = ctx->aux_stream;
+    ZK_HIP(hipStreamWaitEvent(aux, slot.acc_done, 0));
     const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
     int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : 8;
     while ((size_t)kk > plan.nb) kk >>= 1;
     const size_t nchunks = plan.nb / kk;
     const size_t tot = nchunks * plan.nwin;
-    ws.lvl_a.ensure(tot * psz);
-    ws.lvl_b.ensure(tot * psz);
-    ws.lvl_c.ensure(tot * psz);
-    XYZZ<F> *pa = ws.lvl_a.as<XYZZ<F>>(), *pb = ws.lvl_b.as<XYZZ<F>>(), *pc = ws.lvl_c.as<XYZZ<F>>();
+    ctx->red_a.ensure(tot * psz);
+    ctx->red_b.ensure(tot * psz);
+    ctx->red_c.ensure(tot * psz);
+    XYZZ<F> *pa = ctx->red_a.as<XYZZ<F>>(), *pb = ctx->red_b.as<XYZZ<F>>(), *pc = ctx->red_c.as<XYZZ<F>>();
     const unsigned rgrid = (unsigned)((tot + 63) / 64);
     {
-        ScopedKernelTimer kt(ctx, rname, (double)tb);
-        hipLaunchKernelGGL(msm_chunk_sums_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, a.buckets, pa, plan.nb, kk, plan.nwin);
+        ScopedKernelTimer kt(ctx, rname, (double)tb, aux);
+        hipLaunchKernelGGL(msm_chunk_sums_kernel<F>, dim3(rgrid), dim3(64), 0, aux, a.buckets, pa, plan.nb, kk, plan.nwin);
         XYZZ<F> *src = pa, *dst = pb;
         for (size_t d = 1; d < nchunks; d <<= 1) {
-            hipLaunchKernelGGL(msm_scan_step_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, src, dst, nchunks, d, plan.nwin);
+            hipLaunchKernelGGL(msm_scan_step_kernel<F>, dim3(rgrid), dim3(64), 0, aux, src, dst, nchunks, d, plan.nwin);
             XYZZ<F> *t = src; src = dst; dst = t;
         }
-        hipLaunchKernelGGL(msm_chunk_weighted_kernel<F>, dim3(rgrid), dim3(64), 0, ctx->stream, a.buckets, src, pc, plan.nb, kk, plan.nwin);
+        hipLaunchKernelGGL(msm_chunk_weighted_kernel<F>, dim3(rgrid), dim3(64), 0, aux, a.buckets, src, pc, plan.nb, kk, plan.nwin);
         size_t live = nchunks;
         while (live > 1) {
             const size_t half = (live + 1) / 2;
-            hipLaunchKernelGGL(msm_sum_step_kernel<F>, dim3((unsigned)((half * plan.nwin + 63) / 64)), dim3(64), 0, ctx->stream, pc, nchunks, half, live, plan.nwin);
+            hipLaunchKernelGGL(msm_sum_step_kernel<F>, dim3((unsigned)((half * plan.nwin + 63) / 64)), dim3(64), 0, aux, pc, nchunks, half, live, plan.nwin);
             live = half;
         }
     }
+    slot.wsums_dev.ensure(plan.nwin * sizeof(XYZZ<FS>));
+    hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc, nchunks, slot.wsums_dev.as<XYZZ<FS>>(), plan.nwin);
     ZK_HIP(hipGetLastError());
-    ws.lvl_d.ensure(plan.nwin * sizeof(XYZZ<FS>));
-    hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, ctx->stream, pc, nchunks, ws.lvl_d.as<XYZZ<FS>>(), plan.nwin);
-    ZK_HIP(hipGetLastError());
-    std::vector<XYZZ<FS>> wsum(plan.nwin);
-    ZK_HIP(hipMemcpyAsync(wsum.data(), ws.lvl_d.p, plan.nwin * sizeof(XYZZ<FS>), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (slot.host_bytes < plan.nwin * sizeof(XYZZ<FS>)) {
+        if (slot.wsums_host) (void)hipHostFree(slot.wsums_host);
+        slot.host_bytes = 64 * sizeof(XYZZ<FS>) > plan.nwin * sizeof(XYZZ<FS>) ? 64 * sizeof(XYZZ<FS>) : plan.nwin * sizeof(XYZZ<FS>);
+        ZK_HIP(hipHostMalloc(&slot.wsums_host, slot.host_bytes, hipHostMallocDefault));
+    }
+    ZK_HIP(hipMemcpyAsync(slot.wsums_host, slot.wsums_dev.p, plan.nwin * sizeof(XYZZ<FS>), hipMemcpyDeviceToHost, aux));
+    ZK_HIP(hipEventRecord(slot.red_done, aux));
+    slot.active = true;
+}
+
+template <class FS>
+static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
+    (void)ctx;
+    if (!slot.active) return XYZZ<FS>::inf();
+    ZK_HIP(hipEventSynchronize(slot.red_done));
+    const XYZZ<FS> *wsum = reinterpret_cast<const XYZZ<FS> *>(slot.wsums_host);
     // host Horner over windows: sum_w 2^(c*w) W_w
-    XYZZ<FS> total = wsum[plan.nwin - 1];
-    for (int w = plan.nwin - 2; w >= 0; w--) {
-        for (int q = 0; q < plan.c; q++) total = xyzz_dbl(total);
+    XYZZ<FS> total = wsum[slot.nwin - 1];
+    for (int w = slot.nwin - 2; w >= 0; w--) {
+        for (int q = 0; q < slot.c; q++) total = xyzz_dbl(total);
         xyzz_add(total, wsum[w]);
     }
-    (void)tag;
+    slot.active = false;
     return total;
 }
 
+void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot) { msm_enqueue<FqU>(ctx, ws, plan, bases, slot); }
+void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot) { msm_enqueue<Fq2U>(ctx, ws, plan, bases, slot); }
+G1XYZZ msm_g1_collect(zkg16_ctx *ctx, MsmSlot &slot) { return msm_collect<Fq>(ctx, slot); }
+G2XYZZ msm_g2_collect(zkg16_ctx *ctx, MsmSlot &slot) { return msm_collect<Fq2>(ctx, slot); }
+
 G1XYZZ msm_g1_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, const char *tag) {
-    return msm_exec<FqU>(ctx, ws, plan, bases, tag);
+    (void)tag;
+    msm_enqueue<FqU>(ctx, ws, plan, bases, ctx->slots[0]);
+    return msm_collect<Fq>(ctx, ctx->slots[0]);
 }
 G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, const char *tag) {
-    return msm_exec<Fq2U>(ctx, ws, plan, bases, tag);
+    (void)tag;
+    msm_enqueue<Fq2U>(ctx, ws, plan, bases, ctx->slots[0]);
+    return msm_collect<Fq2>(ctx, ctx->slots[0]);
 }
 void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n) {
     if (!n) return;
