@@ -114,6 +114,22 @@ ZKG16_API int zkg16_combine_partials(const uint64_t alpha_g1[12], const uint64_t
                            const uint64_t *partials /* n_ranks x 72 */, const uint8_t *partial_inf /* n_ranks x 5 */,
                            int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]);
 
+/* ---- host-side circuit synthesis (row a2: stays on the host; no ctx, no GPU).  C++ mirrors of the reference's circuits with
+ * the same allocation order (variable k here = variable k in arkworks):
+ *   MatrixCircuit     src/arkworks/matrix_proof_of_work/constraints.rs:78-128 (+ Poseidon hasher.rs:17-40, hashing_utils.rs:15-877)
+ *   FibonacciCircuit  src/arkworks/constraints/fibbonaci.rs:22-48
+ * zkg16_circuit_export yields exactly the arguments of zkg16_r1cs_load / zkg16_witness_load. */
+typedef struct zkg16_circuit zkg16_circuit;
+ZKG16_API int zkg16_circuit_matrix(size_t n, const uint64_t *a /* n*n, row-major */, const uint64_t *b, zkg16_circuit **out);
+ZKG16_API int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit **out);
+ZKG16_API void zkg16_circuit_free(zkg16_circuit *c);
+ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]);
+ZKG16_API int zkg16_circuit_is_satisfied(const zkg16_circuit *c);
+ZKG16_API int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3],
+                         uint64_t *full_assignment /* (num_instance + num_witness) x 4 */);
+/* native Poseidon sponge hash of n Fr elements (Montgomery) — the public inputs hash_a/b/c of the matrix handler */
+ZKG16_API int zkg16_poseidon_hash(const uint64_t *elems, size_t n, uint64_t out[4]);
+
 /* ---- stage entry points (tests / bench; host buffers) ----------------------------------------- */
 /* ark-poly Radix2EvaluationDomain<Fr>: in-place, natural order; inverse => ifft (incl. 1/N);
  * coset => offset g = 7 (coset_fft = g^i then fft; coset_ifft = ifft then g^-i). */

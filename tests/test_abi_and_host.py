@@ -147,16 +147,20 @@ proof, inf = combine_partials(pk["alpha_g1"], pk["beta_g1"], pk["beta_g2"], fr_m
 eproof, einf = oracle.prove(pk, fr_mont(r), fr_mont(s), r1cs, z)
 assert np.array_equal(proof, eproof) and np.array_equal(inf, einf), "rank %d mismatch" % rank
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(OUTDIR, "rank%d.ok" % rank), "w").write("ok")     # per-rank marker: stdout of two ranks interleaves
 '''
 
 
 def test_sharded_exchange_gloo_world2(tmp_path):
     """world_size 2 over gloo on CPU: per-rank partial records -> all_gather -> product's host finish == oracle proof."""
     script = tmp_path / "worker.py"
-    script.write_text("ROOT = %r\n" % ROOT + _WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", OMP_NUM_THREADS="2")
+    script.write_text("ROOT = %r\nOUTDIR = %r\n" % (ROOT, str(tmp_path)) + _WORKER)
+    import socket
+    with socket.socket() as sk:                 # a free port: parallel or repeated runs must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=600)
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()

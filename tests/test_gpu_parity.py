@@ -226,3 +226,30 @@ def test_error_paths(dev):
         dev.lib.zkg16_ntt.argtypes  # noqa
         dev._check(dev.lib.zkg16_ntt(dev.ctx, np.zeros((1, 4), np.uint64), 40, 0, 0))
     assert e.value.status == 2       # domain too large
+
+
+@pytest.mark.parametrize("kind", ["fib10", "fib186", "matrix3", "matrix8"])
+def test_prove_reference_circuits(dev, oracle, kind):
+    """The reference's own circuits (C++ mirrors, csrc/circuits.hip) proved on the GPU: bit-identical to the oracle's proof
+    and satisfying the Groth16 equation in the exponent (known-trapdoor key)."""
+    from zksnark_finalproject_amd.circuits import fibonacci_circuit, matrix_circuit
+    rng = random.Random(hash(kind) & 0xffff)
+    if kind.startswith("fib"):
+        c = fibonacci_circuit(0, 1, int(kind[3:]))                      # bench/fibo.py:26-34: a=0, b=1, rounds <= 186
+    else:
+        n = int(kind[6:])
+        c = matrix_circuit(np.ones((n, n), dtype=np.uint64), np.ones((n, n), dtype=np.uint64))   # bench/matrix.py:11
+    pk, meta = synth.make_pk(oracle, c.r1cs, c.num_vars, rng, point_gen=dev.fixed_base)
+    r, s = P.rand_fr(rng), P.rand_fr(rng)
+    ph = dev.pk_load(pk, c.num_instance)
+    proof, inf = dev.prove(ph, fr_mont(r), fr_mont(s), c.r1cs, c.z)
+    dev.pk_free(ph)
+    eproof, einf = oracle.prove(pk, fr_mont(r), fr_mont(s), c.r1cs, c.z)
+    assert np.array_equal(inf, einf) and np.array_equal(proof, eproof)
+    logs_int = {k: fr_from_mont_vec(meta["logs"][k]) for k in ("a", "b", "l", "h", "gabc")}
+    h_int = fr_from_mont_vec(oracle.witness_map(c.r1cs, c.z))
+    a, b, cc, ok = synth.expected_proof_logs(meta, logs_int, h_int, fr_from_mont_vec(c.z), c.num_instance, r, s)
+    assert ok
+    assert np.array_equal(proof[:12], oracle.point_mul("g1", meta["g1"], fr_canon(a))[0])
+    assert np.array_equal(proof[12:36], oracle.point_mul("g2", meta["g2"], fr_canon(b))[0])
+    assert np.array_equal(proof[36:], oracle.point_mul("g1", meta["g1"], fr_canon(cc))[0])

@@ -38,6 +38,13 @@ SIGNATURES = {
     "zkg16_prove_partial": (C.c_int, [ctxp, H, H, H, u64p, u64p, u64p, u8p]),
     "zkg16_prove_finish": (C.c_int, [ctxp, H, u64p, u64p, u64p, u8p, C.c_int, u64p, u8p]),
     "zkg16_combine_partials": (C.c_int, [u64p, u64p, u64p, u64p, u64p, u64p, u8p, C.c_int, u64p, u8p]),
+    "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),
+    "zkg16_circuit_fibonacci": (C.c_int, [C.c_uint64, C.c_uint64, sz, C.POINTER(vp)]),
+    "zkg16_circuit_free": (None, [vp]),
+    "zkg16_circuit_dims": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
+    "zkg16_circuit_is_satisfied": (C.c_int, [vp]),
+    "zkg16_circuit_export": (C.c_int, [vp, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3), u64p]),
+    "zkg16_poseidon_hash": (C.c_int, [u64p, sz, u64p]),
     "zkg16_ntt": (C.c_int, [ctxp, u64p, sz, C.c_int, C.c_int]),
     "zkg16_msm_g1": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),
     "zkg16_msm_g2": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),

@@ -1,0 +1,65 @@
+"""Host-side circuit synthesis through the C ABI (csrc/circuits.hip): the reference's MatrixCircuit (+ Poseidon) and
+FibonacciCircuit as R1CS (CSR) + full assignment, ready for Device.r1cs_load / Device.witness_load.  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Zkg16Error
+
+
+class SynthesizedCircuit:
+    """num_instance (incl. the constant 1), num_witness, num_constraints, r1cs (dict of CSR triples), z (Montgomery)."""
+
+    def __init__(self, handle):
+        lib = _lib.load()
+        ni, nw, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        nnz = (C.c_size_t * 3)()
+        lib.zkg16_circuit_dims(handle, C.byref(ni), C.byref(nw), C.byref(nc), C.byref(nnz))
+        self.num_instance, self.num_witness, self.num_constraints = ni.value, nw.value, nc.value
+        self.num_vars = ni.value + nw.value
+        self.satisfied = bool(lib.zkg16_circuit_is_satisfied(handle)) if nc.value <= 200000 else None
+        rp = [np.zeros(nc.value + 1, dtype=np.uint64) for _ in range(3)]
+        col = [np.zeros(max(nnz[m], 1), dtype=np.uint32) for m in range(3)]
+        cf = [np.zeros((max(nnz[m], 1), 4), dtype=np.uint64) for m in range(3)]
+        z = np.zeros((self.num_vars, 4), dtype=np.uint64)
+        arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+        rc = lib.zkg16_circuit_export(handle, C.byref(arr(rp)), C.byref(arr(col)), C.byref(arr(cf)), z)
+        if rc:
+            raise Zkg16Error(rc, "circuit export")
+        self.r1cs = dict(a=(rp[0], col[0][:nnz[0]], cf[0][:nnz[0]]), b=(rp[1], col[1][:nnz[1]], cf[1][:nnz[1]]),
+                         c=(rp[2], col[2][:nnz[2]], cf[2][:nnz[2]]), num_inputs=self.num_instance, num_constraints=self.num_constraints)
+        self.z = z
+        self.public_inputs = z[1:self.num_instance].copy()
+        self.domain = 1 << max(self.num_constraints + self.num_instance - 1, 0).bit_length()
+        lib.zkg16_circuit_free(handle)
+
+
+def matrix_circuit(a, b):
+    """MatrixCircuit for u64 matrices a, b (n x n lists/arrays); public inputs = Poseidon hashes of A, B, C = A*B."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    n = a.shape[0]
+    assert a.shape == (n, n) and b.shape == (n, n)
+    h = C.c_void_p()
+    rc = _lib.load().zkg16_circuit_matrix(n, a.reshape(-1), b.reshape(-1), C.byref(h))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_matrix")
+    return SynthesizedCircuit(h)
+
+
+def fibonacci_circuit(a, b, steps):
+    h = C.c_void_p()
+    rc = _lib.load().zkg16_circuit_fibonacci(a, b, steps, C.byref(h))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_fibonacci")
+    return SynthesizedCircuit(h)
+
+
+def poseidon_hash(elems_mont):
+    e = np.ascontiguousarray(elems_mont, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    rc = _lib.load().zkg16_poseidon_hash(e, e.shape[0], out)
+    if rc:
+        raise Zkg16Error(rc, "zkg16_poseidon_hash")
+    return out

@@ -1,0 +1,372 @@
+// Host-side mirror of the reference's circuits (row a2 of the scope table: synthesis stays on the host) — pure host
+// code, no GPU involved.  The reference is Rust (ark-relations / ark-r1cs-std); no Rust toolchain exists in this image,
+// so the same constraint systems are produced here in C++ with the same allocation order, so that variable k of the
+// reference is variable k here:
+//   FibonacciCircuit   /root/reference/src/arkworks/constraints/fibbonaci.rs:22-48
+//   MatrixCircuit      /root/reference/src/arkworks/matrix_proof_of_work/constraints.rs:78-128  (+ alloc.rs:43-49)
+//   Poseidon sponge    /root/reference/src/arkworks/matrix_proof_of_work/hasher.rs:17-40 and the gadget copy at
+//                      hashing/hashing_utils.rs:737-877 (ark-crypto-primitives 0.4 PoseidonSponge / PoseidonSpongeVar);
+//                      parameters = hashing_utils.rs:15-716 (data: poseidon_bls381_params.json -> poseidon_params.inc)
+// Semantics restated from ark-r1cs-std 0.4 `FpVar` (constants fold; Var*Var allocates a product witness and one
+// constraint; addition and scaling are symbolic linear combinations, inlined at `finalize()`), `pow_by_constant`
+// (square-and-multiply from the MSB starting at the constant 1: x^17 = 4 squarings + 1 product = 5 constraints),
+// `enforce_equal` ((a - b) * 1 = 0) and `mul_equals` (a * b = c).  Matrices are exported as CSR with the instance
+// variables first (ark `ConstraintMatrices`).
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/zkg16.h"
+#include "ff.cuh"
+
+using namespace zk;
+
+namespace {
+
+#include "poseidon_params.inc"
+
+Fr fr_from_canon(const uint64_t l[4]) {
+    Fr c;
+    for (int i = 0; i < 4; i++) { c.l[2 * i] = (uint32_t)l[i]; c.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+    return fp_to_mont(c);
+}
+Fr fr_from_u64(uint64_t v) {
+    const uint64_t l[4] = {v, 0, 0, 0};
+    return fr_from_canon(l);
+}
+
+// variable id: instance variables (incl. the constant One = instance 0) and witness variables are numbered separately
+// during synthesis; bit 31 marks a witness.  Final column = instance index, or num_instance + witness index.
+typedef uint32_t VarId;
+const VarId WIT = 0x80000000u;
+
+struct Term { VarId v; Fr c; };
+static bool term_less(const Term &a, const Term &b) { return a.v < b.v; }
+
+// An FpVar: a linear combination over variables (sorted by id) with its value; an empty LC is the constant... no:
+// constants are LCs over the One variable only (`is_const`), mirroring FpVar::Constant.
+struct Lc {
+    std::vector<Term> t;
+    Fr val = Fr::zero();
+    bool is_const = true;    // only the One variable (or nothing) appears
+};
+
+struct Circuit {
+    std::vector<Fr> instance;              // instance[0] = 1
+    std::vector<Fr> witness;
+    std::vector<std::vector<Term>> rows[3];
+
+    Circuit() { instance.push_back(Fr::one()); }
+
+    Lc constant(const Fr &c) const {
+        Lc r;
+        if (!c.is_zero()) r.t.push_back(Term{0, c});
+        r.val = c;
+        r.is_const = true;
+        return r;
+    }
+    Lc new_input(const Fr &v) {
+        instance.push_back(v);
+        Lc r;
+        r.t.push_back(Term{(VarId)(instance.size() - 1), Fr::one()});
+        r.val = v;
+        r.is_const = false;
+        return r;
+    }
+    Lc new_witness(const Fr &v) {
+        witness.push_back(v);
+        Lc r;
+        r.t.push_back(Term{WIT | (VarId)(witness.size() - 1), Fr::one()});
+        r.val = v;
+        r.is_const = false;
+        return r;
+    }
+    static Lc add(const Lc &a, const Lc &b) {
+        Lc r;
+        r.t.reserve(a.t.size() + b.t.size());
+        size_t i = 0, j = 0;
+        while (i < a.t.size() || j < b.t.size()) {
+            if (j == b.t.size() || (i < a.t.size() && a.t[i].v < b.t[j].v)) r.t.push_back(a.t[i++]);
+            else if (i == a.t.size() || b.t[j].v < a.t[i].v) r.t.push_back(b.t[j++]);
+            else {
+                Fr c = fp_add(a.t[i].c, b.t[j].c);
+                if (!c.is_zero()) r.t.push_back(Term{a.t[i].v, c});   // ark's make_row drops zero coefficients
+                i++; j++;
+            }
+        }
+        r.val = fp_add(a.val, b.val);
+        r.is_const = a.is_const && b.is_const;
+        return r;
+    }
+    static Lc scale(const Lc &a, const Fr &c) {
+        Lc r;
+        if (c.is_zero()) { r.is_const = true; return r; }
+        r.t.reserve(a.t.size());
+        for (const Term &x : a.t) r.t.push_back(Term{x.v, fp_mul(x.c, c)});
+        r.val = fp_mul(a.val, c);
+        r.is_const = a.is_const;
+        return r;
+    }
+    static Lc sub(const Lc &a, const Lc &b) { return add(a, scale(b, fp_neg(Fr::one()))); }
+    void enforce(const Lc &a, const Lc &b, const Lc &c) {
+        rows[0].push_back(a.t);
+        rows[1].push_back(b.t);
+        rows[2].push_back(c.t);
+    }
+    // FpVar * FpVar
+    Lc mul(const Lc &a, const Lc &b) {
+        if (a.is_const) return scale(b, a.val);
+        if (b.is_const) return scale(a, b.val);
+        Lc p = new_witness(fp_mul(a.val, b.val));
+        enforce(a, b, p);
+        return p;
+    }
+    Lc square(const Lc &a) { return mul(a, a); }
+    void mul_equals(const Lc &a, const Lc &b, const Lc &c) { enforce(a, b, c); }
+    void enforce_equal(const Lc &a, const Lc &b) { enforce(sub(a, b), constant(Fr::one()), Lc()); }
+    // FieldVar::pow_by_constant (BitIteratorBE::without_leading_zeros)
+    Lc pow_by_constant(const Lc &x, unsigned e) {
+        Lc res = constant(Fr::one());
+        int top = 31;
+        while (top > 0 && !((e >> top) & 1)) top--;
+        for (int i = top; i >= 0; i--) {
+            res = square(res);
+            if ((e >> i) & 1) res = mul(res, x);
+        }
+        return res;
+    }
+    bool satisfied() const {
+        const size_t ni = instance.size();
+        auto eval = [&](const std::vector<Term> &row) {
+            Fr acc = Fr::zero();
+            for (const Term &x : row) {
+                const Fr &v = (x.v & WIT) ? witness[x.v & ~WIT] : instance[x.v];
+                acc = fp_add(acc, fp_mul(x.c, v));
+            }
+            return acc;
+        };
+        (void)ni;
+        for (size_t i = 0; i < rows[0].size(); i++)
+            if (fp_mul(eval(rows[0][i]), eval(rows[1][i])) != eval(rows[2][i])) return false;
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ Poseidon
+struct PoseidonParams {
+    Fr mds[3][3], ark[37][3];
+    PoseidonParams() {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) mds[i][j] = fr_from_canon(POSEIDON_MDS[i][j]);
+        for (int r = 0; r < 37; r++)
+            for (int j = 0; j < 3; j++) ark[r][j] = fr_from_canon(POSEIDON_ARK[r][j]);
+    }
+};
+const PoseidonParams &pparams() {
+    static PoseidonParams p;
+    return p;
+}
+const int P_ROUNDS = POSEIDON_FULL + POSEIDON_PARTIAL, P_HALF = POSEIDON_FULL / 2;
+
+Fr pow17(const Fr &x) {
+    Fr r = x;
+    for (int i = 0; i < 4; i++) r = fp_sqr(r);
+    return fp_mul(r, x);
+}
+// native permutation (ark-crypto-primitives PoseidonSponge::permute)
+void permute_native(Fr st[3]) {
+    const PoseidonParams &p = pparams();
+    for (int r = 0; r < P_ROUNDS; r++) {
+        for (int i = 0; i < 3; i++) st[i] = fp_add(st[i], p.ark[r][i]);
+        const bool full = r < P_HALF || r >= P_HALF + POSEIDON_PARTIAL;
+        if (full) for (int i = 0; i < 3; i++) st[i] = pow17(st[i]);
+        else st[0] = pow17(st[0]);
+        Fr n[3];
+        for (int i = 0; i < 3; i++) {
+            Fr acc = Fr::zero();
+            for (int j = 0; j < 3; j++) acc = fp_add(acc, fp_mul(st[j], p.mds[i][j]));
+            n[i] = acc;
+        }
+        for (int i = 0; i < 3; i++) st[i] = n[i];
+    }
+}
+// sponge.absorb(&elems); sponge.squeeze_native_field_elements(1)[0]  (hasher.rs:17-27)
+Fr poseidon_hash_native(const Fr *elems, size_t n) {
+    Fr st[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t idx = 0, pos = 0;             // pos = next_absorb_index
+    while (idx < n) {
+        if (pos == POSEIDON_RATE) { permute_native(st); pos = 0; }
+        st[POSEIDON_CAP + pos] = fp_add(st[POSEIDON_CAP + pos], elems[idx]);
+        pos++; idx++;
+    }
+    permute_native(st);                  // squeeze from Absorbing mode permutes first
+    return st[POSEIDON_CAP];
+}
+// the same through the gadget (PoseidonSpongeVar): returns state[1] as an FpVar
+void permute_gadget(Circuit &cs, Lc st[3]) {
+    const PoseidonParams &p = pparams();
+    for (int r = 0; r < P_ROUNDS; r++) {
+        for (int i = 0; i < 3; i++) st[i] = Circuit::add(st[i], cs.constant(p.ark[r][i]));
+        const bool full = r < P_HALF || r >= P_HALF + POSEIDON_PARTIAL;
+        if (full) for (int i = 0; i < 3; i++) st[i] = cs.pow_by_constant(st[i], POSEIDON_ALPHA);
+        else st[0] = cs.pow_by_constant(st[0], POSEIDON_ALPHA);
+        Lc n[3];
+        for (int i = 0; i < 3; i++) {
+            Lc cur = cs.constant(Fr::zero());
+            for (int j = 0; j < 3; j++) cur = Circuit::add(cur, Circuit::scale(st[j], p.mds[i][j]));
+            n[i] = cur;
+        }
+        for (int i = 0; i < 3; i++) st[i] = n[i];
+    }
+}
+Lc poseidon_hash_gadget(Circuit &cs, const std::vector<Lc> &elems) {
+    Lc st[3] = {cs.constant(Fr::zero()), cs.constant(Fr::zero()), cs.constant(Fr::zero())};
+    size_t pos = 0;
+    for (const Lc &e : elems) {
+        if (pos == POSEIDON_RATE) { permute_gadget(cs, st); pos = 0; }
+        st[POSEIDON_CAP + pos] = Circuit::add(st[POSEIDON_CAP + pos], e);
+        pos++;
+    }
+    permute_gadget(cs, st);
+    return st[POSEIDON_CAP];
+}
+
+}  // namespace
+
+struct zkg16_circuit {
+    Circuit cs;
+    std::vector<Fr> public_inputs;     // instance[1..]
+};
+
+extern "C" {
+
+// FibonacciCircuit { a, b, num_of_steps, result } with result computed in Fr (the reference's u128 helper overflows
+// above 186 rounds: SURVEY.md F8).
+int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit **out) {
+    if (!out) return ZKG16_ERR_BAD_ARG;
+    auto c = new (std::nothrow) zkg16_circuit();
+    if (!c) return ZKG16_ERR_OOM;
+    Circuit &cs = c->cs;
+    const Fr fa = fr_from_u64(a), fb = fr_from_u64(b);
+    // fibbonaci_handler.rs:13-27 semantics: after `steps` rounds the result is f_{steps} of the (a, b) sequence
+    Fr x = fa, y = fb, res = steps == 0 ? Fr::zero() : fb;
+    for (size_t i = 0; i < steps; i++) { res = fp_add(x, y); x = y; y = res; }
+    Lc f2 = cs.new_input(fa), f1 = cs.new_input(fb), saved = cs.new_input(res);
+    Lc fi = cs.new_witness(Fr::zero());
+    for (size_t i = 0; i < steps; i++) {
+        fi = Circuit::add(f1, f2);
+        cs.enforce_equal(fi, Circuit::add(f1, f2));
+        f2 = f1;
+        f1 = fi;
+    }
+    cs.enforce_equal(fi, saved);
+    *out = c;
+    return ZKG16_OK;
+}
+
+// MatrixCircuit::new(matrix_a, matrix_b, hash_a, hash_b, hash_c) with the hashes computed natively as the handler does
+// (matrix_proof.rs:104-125).  a, b: n*n u64 entries, row-major.
+int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_circuit **out) {
+    if (!out || !a || !b || n == 0 || n > 1024) return ZKG16_ERR_BAD_ARG;
+    auto c = new (std::nothrow) zkg16_circuit();
+    if (!c) return ZKG16_ERR_OOM;
+    try {
+        Circuit &cs = c->cs;
+        const size_t nn = n * n;
+        std::vector<Fr> av(nn), bv(nn), cv(nn, Fr::zero());
+        for (size_t i = 0; i < nn; i++) { av[i] = fr_from_u64(a[i]); bv[i] = fr_from_u64(b[i]); }
+        for (size_t i = 0; i < n; i++)
+            for (size_t j = 0; j < n; j++) {
+                Fr s = Fr::zero();
+                for (size_t k = 0; k < n; k++) s = fp_add(s, fp_mul(av[i * n + k], bv[k * n + j]));
+                cv[i * n + j] = s;
+            }
+        const Fr hash_a = poseidon_hash_native(av.data(), nn), hash_b = poseidon_hash_native(bv.data(), nn),
+                 hash_c = poseidon_hash_native(cv.data(), nn);
+        // generate_constraints (constraints.rs:101-128)
+        Lc in_a = cs.new_input(hash_a), in_b = cs.new_input(hash_b);
+        std::vector<Lc> ma(nn), mb(nn);
+        for (size_t i = 0; i < nn; i++) ma[i] = cs.new_witness(av[i]);
+        for (size_t i = 0; i < nn; i++) mb[i] = cs.new_witness(bv[i]);
+        Lc ha = poseidon_hash_gadget(cs, ma);
+        Lc hb = poseidon_hash_gadget(cs, mb);
+        cs.enforce_equal(ha, in_a);
+        cs.enforce_equal(hb, in_b);
+        // matrix_mul (constraints.rs:78-99)
+        std::vector<Lc> mc(nn);
+        for (size_t i = 0; i < nn; i++) mc[i] = cs.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
+        for (size_t i = 0; i < n; i++)
+            for (size_t j = 0; j < n; j++) {
+                Lc sum = cs.new_witness(Fr::zero());
+                for (size_t k = 0; k < n; k++) {
+                    const Lc &ij = ma[i * n + k], &jk = mb[k * n + j];
+                    Lc product = cs.mul(ij, jk);            // `*`: product witness + constraint (:91)
+                    sum = Circuit::add(sum, product);       // symbolic (:92)
+                    cs.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
+                }
+                mc[i * n + j] = sum;
+            }
+        Lc hc = poseidon_hash_gadget(cs, mc);
+        Lc in_c = cs.new_input(hash_c);
+        cs.enforce_equal(hc, in_c);
+    } catch (const std::bad_alloc &) {
+        delete c;
+        return ZKG16_ERR_OOM;
+    }
+    *out = c;
+    return ZKG16_OK;
+}
+
+void zkg16_circuit_free(zkg16_circuit *c) { delete c; }
+
+int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]) {
+    if (!c) return ZKG16_ERR_BAD_ARG;
+    if (num_instance) *num_instance = c->cs.instance.size();
+    if (num_witness) *num_witness = c->cs.witness.size();
+    if (num_constraints) *num_constraints = c->cs.rows[0].size();
+    if (nnz)
+        for (int m = 0; m < 3; m++) {
+            size_t k = 0;
+            for (const auto &r : c->cs.rows[m]) k += r.size();
+            nnz[m] = k;
+        }
+    return ZKG16_OK;
+}
+
+int zkg16_circuit_is_satisfied(const zkg16_circuit *c) { return c ? (c->cs.satisfied() ? 1 : 0) : 0; }
+
+// ConstraintMatrices as CSR (caller-allocated: row_ptr[m] has num_constraints + 1 entries, col/coeff nnz[m]) and the
+// full assignment z = instance || witness (Montgomery limbs).
+int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3], uint64_t *z) {
+    if (!c || !row_ptr || !col || !coeff || !z) return ZKG16_ERR_BAD_ARG;
+    const size_t ni = c->cs.instance.size();
+    for (int m = 0; m < 3; m++) {
+        size_t k = 0;
+        row_ptr[m][0] = 0;
+        for (size_t i = 0; i < c->cs.rows[m].size(); i++) {
+            // instance columns first, then witnesses: sort by final column (ids are already ordered that way)
+            for (const Term &t : c->cs.rows[m][i]) {
+                col[m][k] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
+                memcpy(coeff[m] + 4 * k, t.c.l, 32);
+                k++;
+            }
+            row_ptr[m][i + 1] = k;
+        }
+    }
+    memcpy(z, c->cs.instance.data(), ni * 32);
+    memcpy(z + 4 * ni, c->cs.witness.data(), c->cs.witness.size() * 32);
+    return ZKG16_OK;
+}
+
+// native sponge hash of n Montgomery Fr elements (hasher.rs:17-27)
+int zkg16_poseidon_hash(const uint64_t *elems, size_t n, uint64_t out[4]) {
+    if ((!elems && n) || !out) return ZKG16_ERR_BAD_ARG;
+    const Fr h = poseidon_hash_native(reinterpret_cast<const Fr *>(elems), n);
+    memcpy(out, h.l, 32);
+    return ZKG16_OK;
+}
+
+}  // extern "C"
