@@ -193,18 +193,20 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
 
     // queue all five MSMs (the G2 one first: its long reduction then hides behind the four G1 accumulations), then
     // collect: each MSM's host Horner overlaps the device work still queued behind it
-    msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+    if (!ctx->opt_g2_last) msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
     msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    if (ctx->opt_g2_last) msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
     double tprev = now_ms();
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
-    out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
+    if (!ctx->opt_g2_last) { out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7); }
     out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
     out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
     out.a = msm_g1_collect(ctx, ctx->slots[3]); lap(5);
     out.b1 = msm_g1_collect(ctx, ctx->slots[4]); lap(6);
+    if (ctx->opt_g2_last) { out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7); }
     ZK_HIP(hipEventSynchronize(ev[2]));
     float ms;
     // [1] witness map, [2] digits+sort (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2 (collected in
@@ -379,6 +381,10 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "window_bits")) {
         if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "g2_last")) {
+        ctx->opt_g2_last = value != 0;
         return ZKG16_OK;
     }
     if (!strcmp(name, "reduce_chunk")) {

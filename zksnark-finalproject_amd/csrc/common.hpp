@@ -126,6 +126,7 @@ struct zkg16_ctx {
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
     int opt_reduce_chunk = 0;
+    bool opt_g2_last = false;
     int num_cus = 256;
 };
 

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, const
 //   chunk_weighted  run = incl_{c+1}; for b in chunk, top down: run += B_b; acc += run     (2K adds deep)
 //   sum_step x log  W = sum_c acc_c  (pairwise halving)                     (1 add deep each)
 template <class F>
-__global__ void __launch_bounds__(64) msm_chunk_sums_kernel(const XYZZ<F> *buckets, XYZZ<F> *sums, size_t nb, int k, int nwin) {
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_chunk_sums_kernel(const XYZZ<F> *buckets, XYZZ<F> *sums, size_t nb, int k, int nwin) {
     const size_t nchunks = nb / k;
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nchunks * (size_t)nwin) return;
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(64) msm_chunk_sums_kernel(const XYZZ<F> *bucke
 
 // out[c] = in[c] + in[c + d]  (within a window of m entries; beyond the end: unchanged)
 template <class F>
-__global__ void __launch_bounds__(64) msm_scan_step_kernel(const XYZZ<F> *in, XYZZ<F> *out, size_t m, size_t d, int nwin) {
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_scan_step_kernel(const XYZZ<F> *in, XYZZ<F> *out, size_t m, size_t d, int nwin) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= m * (size_t)nwin) return;
     const size_t c = id % m;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64) msm_scan_step_kernel(const XYZZ<F> *in, XY
 }
 
 template <class F>
-__global__ void __launch_bounds__(64) msm_chunk_weighted_kernel(const XYZZ<F> *buckets, const XYZZ<F> *incl, XYZZ<F> *out, size_t nb, int k, int nwin) {
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_chunk_weighted_kernel(const XYZZ<F> *buckets, const XYZZ<F> *incl, XYZZ<F> *out, size_t nb, int k, int nwin) {
     const size_t nchunks = nb / k;
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nchunks * (size_t)nwin) return;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64) msm_chunk_weighted_kernel(const XYZZ<F> *b
 
 // buf[c] += buf[c + half] for c < half (within each window of `stride` entries)
 template <class F>
-__global__ void __launch_bounds__(64) msm_sum_step_kernel(XYZZ<F> *buf, size_t stride, size_t half, size_t live, int nwin) {
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_sum_step_kernel(XYZZ<F> *buf, size_t stride, size_t half, size_t live, int nwin) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= half * (size_t)nwin) return;
     const size_t w = id / half, c = id - w * half;
