@@ -54,6 +54,22 @@ def test_ntt_full_size(dev, oracle, log_n):
     assert np.array_equal(g, oracle.ntt(a, True, False))
 
 
+@pytest.mark.parametrize("log_n", [23, 24])
+def test_ntt_three_pass(dev, oracle, log_n):
+    """Domains above 2^22 (the literal 128x128 config needs 2^24) take a third pass: oracle equality + round trip."""
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    a = oracle.fr_from_canonical(rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64))
+    oracle.set_threads(8)
+    f = dev.ntt(a, False, True)
+    assert np.array_equal(f, oracle.ntt(a, False, True))
+    assert np.array_equal(dev.ntt(f, True, True), a)
+    if log_n == 23:
+        g = dev.ntt(a, True, False)
+        assert np.array_equal(g, oracle.ntt(a, True, False))
+    oracle.set_threads(1)
+
+
 # ---------------------------------------------------------------------------------------------- fixed base / MSM
 def test_fixed_base_vs_oracle(dev, oracle):
     rng = random.Random(5)

@@ -31,8 +31,8 @@ reps = 2
 for _ in range(reps):
     dev.prove_resident(ph, rh, wh, r, s)
 dev.kernel_timing(False)
-names = ["spmv_kernel", "ntt_pass_cols", "ntt_pass_rows", "pointwise_h_kernel", "fr_from_mont_kernel", "msm_digits_kernel", "msm_scan_kernel",
-         "msm_scatter_kernel", "msm_accumulate_g1", "msm_fixup_g1", "msm_fixup_long_g1", "msm_reduce_g1", "msm_accumulate_g2", "msm_fixup_g2",
+names = ["spmv_kernel", "ntt_pass_cols", "ntt_pass_rows", "pointwise_h_kernel", "fr_from_mont_kernel", "msm_digits_kernel", "msm_radix_sort", "msm_offsets_kernel",
+         "msm_accumulate_g1", "msm_fixup_g1", "msm_fixup_long_g1", "msm_reduce_g1", "msm_accumulate_g2", "msm_fixup_g2",
          "msm_fixup_long_g2", "msm_reduce_g2"]
 tot = 0
 for k in names:

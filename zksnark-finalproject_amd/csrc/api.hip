@@ -261,7 +261,7 @@ int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const
     int log_n = 0;
     while (((size_t)1 << log_n) < dom) log_n++;
     if (log_n > 32) return ZKG16_ERR_DOMAIN_TOO_LARGE;      // ark: SynthesisError::PolynomialDegreeTooLarge
-    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;      // build limit of the two-pass NTT
+    if (log_n > 28) return ZKG16_ERR_DOMAIN_TOO_LARGE;      // build limit (three-pass NTT covers 2^31; 32-bit entry indices cap the MSMs)
     auto r = std::make_unique<R1csDev>();
     r->num_instance = num_instance;
     r->num_constraints = num_constraints;
@@ -592,7 +592,7 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
 int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int coset) {
     if (!data) return ZKG16_ERR_BAD_ARG;
     if (log_n > 32) return ZKG16_ERR_DOMAIN_TOO_LARGE;
-    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    if (log_n > 28) return ZKG16_ERR_DOMAIN_TOO_LARGE;
     ZK_API_BEGIN(ctx)
     const size_t n = (size_t)1 << log_n;
     DevBuf d(n * sizeof(Fr)), t(n * sizeof(Fr));
@@ -605,7 +605,7 @@ int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int cos
 
 int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int iters, float *ms_per_iter) {
     if (!ms_per_iter || iters < 1) return ZKG16_ERR_BAD_ARG;
-    if (log_n > 22) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    if (log_n > 28) return ZKG16_ERR_DOMAIN_TOO_LARGE;
     ZK_API_BEGIN(ctx)
     const size_t n = (size_t)1 << log_n;
     DevBuf d(n * sizeof(Fr)), t(n * sizeof(Fr));

@@ -99,7 +99,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list, tile_sums;
+    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list, sort_temp;
 };
 
 }  // namespace zk
@@ -165,6 +165,7 @@ struct MsmPlan {
     int seg_len = 0;
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
+void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
 void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);

@@ -5,9 +5,9 @@
 // value is pinned by the reference; the schedule below is MI355X-first:
 //
 //  scalar side (once per scalar vector, shared by every MSM over it — A, B1, B2 and L all use z):
-//    msm_digits   signed radix-2^c digits (c up to 16), one key per (window, scalar), bucket histogram
-//    msm_scan     exclusive prefix sum of the W * 2^(c-1) bucket sizes
-//    msm_scatter  counting-sort scatter of (index, sign) entries into bucket order
+//    msm_digits   signed radix-2^c digits (c up to 16) -> one 64-bit key (bucket id | index | sign) per (window, scalar)
+//    radix sort   rocPRIM device radix sort on the bucket-id bits (sort.hip) — stable, so bucket order is reproducible
+//    msm_offsets  bucket boundaries by binary search in the sorted keys
 //  base side (per MSM):
 //    msm_accumulate  one lane per fixed-length SEGMENT of the bucket-sorted entry list (not per bucket), so
 //                    every lane of every wave performs exactly the same number of XYZZ mixed additions no matter
@@ -50,9 +50,9 @@ __device__ __forceinline__ void stv(T *p, const T &v) {
 }
 
 // ------------------------------------------------------------------------------------------------ scalar side
-// keys[w*n + i] = 0 (digit 0) or 1 + ((|d|-1) << 1 | neg)
+// keys[w*n + i] = bucket id << 32 | i << 1 | neg, bucket id = w * 2^(c-1) + |d| - 1, or `invalid_bucket` (sorts last) for digit 0
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars, size_t n, int c, int nwin, size_t nb,
-                                                         uint32_t *keys, uint32_t *counts) {
+                                                         uint64_t *keys, uint32_t invalid_bucket) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[9];
@@ -97,96 +97,22 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars
         } else if (v != 0) {
             key = 1u + (((v - 1u) << 1) | flipbit);
         }
-        keys[(size_t)w * n + i] = key;
-        if (key) atomicAdd(&counts[(size_t)w * nb + ((key - 1u) >> 1)], 1u);
+        const uint32_t g = key ? (uint32_t)((size_t)w * nb + ((key - 1u) >> 1)) : invalid_bucket;
+        keys[(size_t)w * n + i] = ((uint64_t)g << 32) | (uint64_t)(((uint32_t)i << 1) | ((key - 1u) & 1u));
     }
 }
 
-// exclusive scan of counts[0..total) -> offsets[0..total] in three coalesced steps:
-//   tile sums (4096 entries per workgroup) -> scan of the tile sums (one workgroup) -> per-tile scan + tile offset
-static constexpr int SCAN_TILE = 4096;      // 256 threads x 16 entries
-
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *sh, uint32_t *total) {
-    // wave-level inclusive scan by shuffles, then a 4-entry LDS combine
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
+// offsets[g] = first position of the sorted entry list whose bucket id is >= g  (g = 0 .. total_buckets; the last one is the
+// number of valid entries: digit-0 keys carry bucket id = total_buckets and sort behind everything)
+__global__ void __launch_bounds__(256) msm_offsets_kernel(const uint2 *sorted, size_t count, uint32_t *offsets, size_t total_buckets) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > total_buckets) return;
+    size_t lo = 0, hi = count;                    // answer in [lo, hi]
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (sorted[mid].y < (uint32_t)g) lo = mid + 1; else hi = mid;
     }
-    if (lane == 63) sh[wave] = x;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += sh[w];
-    if (total) *total = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return base + x - v;
-}
-
-__global__ void __launch_bounds__(256) msm_scan_tile_sums_kernel(const uint32_t *counts, uint32_t *tile_sums, size_t total) {
-    __shared__ uint32_t sh[4];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const size_t i = base + (size_t)k * 256 + threadIdx.x;
-        if (i < total) sum += counts[i];
-    }
-    uint32_t tot;
-    (void)block_exclusive_scan_256(sum, sh, &tot);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of up to 256*16 tile sums in place; writes the grand total to *grand
-__global__ void __launch_bounds__(256) msm_scan_tiles_kernel(uint32_t *tile_sums, size_t ntiles, uint32_t *grand) {
-    __shared__ uint32_t sh[4];
-    __shared__ uint32_t carry_sh;
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (size_t base = 0; base < ntiles; base += 256) {
-        const size_t i = base + threadIdx.x;
-        const uint32_t v = i < ntiles ? tile_sums[i] : 0;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan_256(v, sh, &tot);
-        const uint32_t carry = carry_sh;
-        if (i < ntiles) tile_sums[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *grand = carry_sh;
-}
-
-__global__ void __launch_bounds__(256) msm_scan_apply_kernel(const uint32_t *counts, const uint32_t *tile_offsets, uint32_t *offsets, size_t total) {
-    __shared__ uint32_t sh[4];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;   // 16 consecutive entries per thread
-    uint32_t v[16];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        v[k] = base + k < total ? counts[base + k] : 0;
-        sum += v[k];
-    }
-    uint32_t run = tile_offsets[blockIdx.x] + block_exclusive_scan_256(sum, sh, nullptr);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if (base + k < total) offsets[base + k] = run;
-        run += v[k];
-    }
-}
-
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *keys, size_t n, int nwin, size_t nb,
-                                                          const uint32_t *offsets, uint32_t *cursors, uint2 *entries) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * (size_t)nwin) return;
-    const uint32_t key = keys[idx];
-    if (!key) return;
-    const size_t w = idx / n, i = idx - w * n;
-    const size_t g = w * nb + ((key - 1u) >> 1);
-    const uint32_t pos = offsets[g] + atomicAdd(&cursors[g], 1u);
-    // (base index, sign) and the bucket id travel together: the accumulation loop never touches the offset table
-    entries[pos] = make_uint2(((uint32_t)i << 1) | ((key - 1u) & 1u), (uint32_t)g);
+    offsets[g] = (uint32_t)lo;
 }
 
 // ------------------------------------------------------------------------------------------------ base side
@@ -456,39 +382,30 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     plan.nseg = 0;
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
-    ws.keys.ensure(n * plan.nwin * sizeof(uint32_t));
-    ws.entries.ensure(n * plan.nwin * sizeof(uint2));
-    ws.counts.ensure(tb * sizeof(uint32_t));
-    ws.cursors.ensure(tb * sizeof(uint32_t));
+    const size_t tot = n * (size_t)plan.nwin;
+    ws.keys.ensure(tot * sizeof(uint64_t));
+    ws.entries.ensure(tot * sizeof(uint64_t));
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
-    ZK_HIP(hipMemsetAsync(ws.counts.p, 0, tb * sizeof(uint32_t), ctx->stream));
-    ZK_HIP(hipMemsetAsync(ws.cursors.p, 0, tb * sizeof(uint32_t), ctx->stream));
     {
         ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const uint32_t *>(scalars_canonical), n, plan.c, plan.nwin, plan.nb,
-                           ws.keys.as<uint32_t>(), ws.counts.as<uint32_t>());
+                           ws.keys.as<uint64_t>(), (uint32_t)tb);
     }
+    unsigned key_bits = 1;
+    while (((size_t)1 << key_bits) <= tb) key_bits++;
+    msm_sort_keys(ctx, ws, tot, key_bits);
     {
-        const size_t ntiles = (tb + SCAN_TILE - 1) / SCAN_TILE;
-        ws.tile_sums.ensure((ntiles + 1) * sizeof(uint32_t));
-        uint32_t *tiles = ws.tile_sums.as<uint32_t>();
-        ScopedKernelTimer kt(ctx, "msm_scan_kernel", (double)tb, ctx->stream);
-        hipLaunchKernelGGL(msm_scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles, tb);
-        hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, tiles, ntiles, ws.offsets.as<uint32_t>() + tb);
-        hipLaunchKernelGGL(msm_scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, ws.counts.as<uint32_t>(), tiles,
-                           ws.offsets.as<uint32_t>(), tb);
-    }
-    {
-        const size_t tot = n * (size_t)plan.nwin;
-        ScopedKernelTimer kt(ctx, "msm_scatter_kernel", (double)tot, ctx->stream);
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ws.keys.as<uint32_t>(), n, plan.nwin, plan.nb, ws.offsets.as<uint32_t>(), ws.cursors.as<uint32_t>(),
-                           ws.entries.as<uint2>());
+        ScopedKernelTimer kt(ctx, "msm_offsets_kernel", (double)tb, ctx->stream);
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3((unsigned)((tb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ws.entries.as<uint2>(), tot, ws.offsets.as<uint32_t>(), tb);
     }
     ZK_HIP(hipGetLastError());
     // the exact entry count stays on the device (offsets[tb]); launches are sized by the bound n * windows
     plan.total_entries = n * (size_t)plan.nwin;
+    // segment length: 64 entries until that would exceed ~2^18 segments (more than enough lanes to fill 256 CUs), then
+    // longer segments — keeps the average bucket inside one segment at large n and the fix-up lists short
+    while (plan.seg_len < 2048 && plan.total_entries / plan.seg_len > ((size_t)1 << 18)) plan.seg_len <<= 1;
     plan.nseg = (plan.total_entries + plan.seg_len - 1) / plan.seg_len;
 }
 

@@ -61,8 +61,12 @@ struct NttPassArgs {
     const Fr *post;    // optional per-output-index multiplier (coset ifft), else null
     Fr post_const;     // used when post_const_on (plain ifft: N^-1)
     int post_const_on;
-    int log_n, log_n1, log_n2;
+    int log_n, log_n1, log_n2;   // log_n = size of the w table (whole transform); this pass splits a 2^(log_n1+log_n2) sub-transform
     int inverse;
+    // three-pass transforms (N > 2^22): passes 2 and 3 run batched over blockIdx.y = k0 on the rows of the outer split
+    int tw_shift;                // inter-pass twiddle index is (i2*k1) << tw_shift   (w_M = w_N^(2^tw_shift))
+    size_t batch_stride;         // elements between consecutive batches in `in` (and in `out` for in-place passes)
+    int out_stride_log;          // rows pass: final index = batch + (k << out_stride_log)
 };
 
 // DIF over `ncols` independent sub-transforms of size 2^log_m laid out back to back in the LDS tile.
@@ -115,12 +119,14 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
     const unsigned nmask = (1u << a.log_n) - 1u;
     const size_t n2 = (size_t)1 << a.log_n2;
     const size_t col0 = (size_t)blockIdx.x * C;
+    const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
+    Fr *out = a.out + (size_t)blockIdx.y * a.batch_stride;
 
     stage_twiddles(s_tw, tw_stride, a.w, a.log_n, a.log_n1, a.inverse);
     for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
         const int c = t & (C - 1), i1 = t >> log_c;
         const size_t gi = (size_t)i1 * n2 + col0 + c;
-        Fr v = gld(a.in + gi);
+        Fr v = gld(in + gi);
         if (a.pre) v = fp_mul(v, gld(a.pre + gi));
         lds_st(s_data, NTT_TILE, (c << a.log_n1) + i1, v);
     }
@@ -130,10 +136,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         const int c = t & (C - 1), k1 = t >> log_c;
         Fr v = lds_ld(s_data, NTT_TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
         const size_t i2 = col0 + c;
-        unsigned e = (unsigned)((i2 * (size_t)k1) & nmask);    // inter-pass twiddle w_N^(i2*k1)
+        unsigned e = (unsigned)(((i2 * (size_t)k1) << a.tw_shift) & nmask);    // inter-pass twiddle w_M^(i2*k1), w_M = w_N^(2^tw_shift)
         if (a.inverse) e = ((1u << a.log_n) - e) & nmask;
         if (e) v = fp_mul(v, gld(a.w + e));
-        gst(a.out + (size_t)k1 * n2 + i2, v);
+        gst(out + (size_t)k1 * n2 + i2, v);
     }
     (void)n1;
 }
@@ -150,6 +156,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     const size_t n2 = (size_t)1 << a.log_n2;
     const size_t row0 = (size_t)blockIdx.x * R;
     const size_t n1_rows = n1;                        // rows that exist (R may exceed N1 for tiny transforms)
+    const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
 
     stage_twiddles(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
     for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS) {
@@ -157,7 +164,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         Fr v = Fr::zero();
         if (row0 + r < n1_rows) {
             const size_t gi = (row0 + r) * n2 + i2;
-            v = gld(a.in + gi);
+            v = gld(in + gi);
             if (a.pre) v = fp_mul(v, gld(a.pre + gi));
         }
         lds_st(s_data, NTT_TILE, t, v);
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
         const int r = t & (R - 1), k2 = t >> log_r;
         if (row0 + r >= n1_rows) continue;
         Fr v = lds_ld(s_data, NTT_TILE, (r << a.log_n2) + bitrev(k2, a.log_n2));
-        const size_t k = (row0 + r) + n1 * (size_t)k2;
+        const size_t k = (size_t)blockIdx.y + (((row0 + r) + n1 * (size_t)k2) << a.out_stride_log);
         if (a.post) v = fp_mul(v, gld(a.post + k));
         else if (a.post_const_on) v = fp_mul(v, a.post_const);
         gst(a.out + k, v);
@@ -231,7 +238,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
-    if (log_n > 2 * NTT_MAX_SUB_LOG) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^22", __FILE__, __LINE__};
+    if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
     const size_t n = (size_t)1 << log_n;
     NttPassArgs a;
@@ -243,6 +250,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
     const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
     const int post_const_on = (inverse && !coset) ? 1 : 0;
     a.post_const = t->n_inv;
+    auto lds_bytes = [](int log_m) { return (size_t)8 * 4 * (NTT_TILE + (log_m > 0 ? (1 << (log_m - 1)) : 1)); };
 
     if (log_n <= NTT_MAX_SUB_LOG) {
         a.log_n1 = 0;
@@ -252,32 +260,43 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         a.pre = pre;
         a.post = post;
         a.post_const_on = post_const_on;
-        const size_t lds = (size_t)8 * 4 * (NTT_TILE + (log_n > 0 ? (1 << (log_n - 1)) : 1));
         ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-        hipLaunchKernelGGL(ntt_pass_rows, dim3(1), dim3(NTT_THREADS), lds, ctx->stream, a);
+        hipLaunchKernelGGL(ntt_pass_rows, dim3(1), dim3(NTT_THREADS), lds_bytes(log_n), ctx->stream, a);
     } else {
-        a.log_n2 = log_n / 2;
-        a.log_n1 = log_n - a.log_n2;
+        // N = N0 * M (N0 = 1 for N <= 2^22): [outer column pass over N0] then the two-pass transform of size M, batched over k0 < N0
+        const int log_m = log_n <= 2 * NTT_MAX_SUB_LOG ? log_n : 2 * NTT_MAX_SUB_LOG;
+        const int log_n0 = log_n - log_m;
+        if (log_n0 > 0) {
+            NttPassArgs p0 = a;
+            p0.in = data; p0.out = data; p0.pre = pre;
+            p0.log_n1 = log_n0; p0.log_n2 = log_m;
+            const unsigned grid = (unsigned)(((size_t)1 << log_m) >> (NTT_TILE_LOG - log_n0));
+            ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
+            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid), dim3(NTT_THREADS), lds_bytes(log_n0), ctx->stream, p0);
+        }
+        a.log_n2 = log_m / 2;
+        a.log_n1 = log_m - a.log_n2;
+        const unsigned batches = 1u << log_n0;
         {
             NttPassArgs p1 = a;
-            p1.in = data;
-            p1.out = data;
-            p1.pre = pre;
-            const size_t lds = (size_t)8 * 4 * (NTT_TILE + (1 << (a.log_n1 - 1)));
+            p1.in = data; p1.out = data;
+            p1.pre = log_n0 > 0 ? nullptr : pre;
+            p1.tw_shift = log_n0;
+            p1.batch_stride = (size_t)1 << log_m;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (NTT_TILE_LOG - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid), dim3(NTT_THREADS), lds, ctx->stream, p1);
+            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid, batches), dim3(NTT_THREADS), lds_bytes(a.log_n1), ctx->stream, p1);
         }
         {
             NttPassArgs p2 = a;
-            p2.in = data;
-            p2.out = tmp;
+            p2.in = data; p2.out = tmp;
             p2.post = post;
             p2.post_const_on = post_const_on;
-            const size_t lds = (size_t)8 * 4 * (NTT_TILE + (1 << (a.log_n2 - 1)));
+            p2.batch_stride = (size_t)1 << log_m;
+            p2.out_stride_log = log_n0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n1) >> (NTT_TILE_LOG - a.log_n2));
             ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-            hipLaunchKernelGGL(ntt_pass_rows, dim3(grid), dim3(NTT_THREADS), lds, ctx->stream, p2);
+            hipLaunchKernelGGL(ntt_pass_rows, dim3(grid, batches), dim3(NTT_THREADS), lds_bytes(a.log_n2), ctx->stream, p2);
         }
     }
     ZK_HIP(hipGetLastError());
