@@ -114,6 +114,17 @@ ZKG16_API int zkg16_combine_partials(const uint64_t alpha_g1[12], const uint64_t
                            const uint64_t *partials /* n_ranks x 72 */, const uint8_t *partial_inf /* n_ranks x 5 */,
                            int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]);
 
+/* ---- Groth16 circuit-specific setup on the device from a caller-supplied trapdoor (scope row f-1).  Replaces
+ * `Groth16::<Bls12_381>::setup(circuit, &mut rng)` (matrix_proof.rs:129, fibbonaci_handler.rs:107, prime_snark.rs:112-113): the caller
+ * draws trapdoor = tau | alpha | beta | gamma | delta (5 x 4 limbs, Montgomery) and the generators g1, g2 from its rng as upstream's
+ * generate_random_parameters_with_reduction does.  Outputs are caller-allocated with the lengths of zkg16_pk_load
+ * (a/b_g1/b_g2: num_variables, h: N-1, l: num_witness) plus the verifying-key elements. */
+ZKG16_API int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12], const uint64_t g2_gen[24],
+                uint64_t *a_query, uint8_t *a_inf, uint64_t *b_g1_query, uint8_t *b_g1_inf, uint64_t *b_g2_query, uint8_t *b_g2_inf,
+                uint64_t *h_query, uint64_t *l_query, uint8_t *l_inf,
+                uint64_t alpha_g1[12], uint64_t beta_g1[12], uint64_t beta_g2[24], uint64_t delta_g1[12], uint64_t delta_g2[24],
+                uint64_t gamma_g2[24], uint64_t *gamma_abc_g1 /* num_instance x 12 */);
+
 /* ---- host-side circuit synthesis (row a2: stays on the host; no ctx, no GPU).  C++ mirrors of the reference's circuits with
  * the same allocation order (variable k here = variable k in arkworks):
  *   MatrixCircuit     src/arkworks/matrix_proof_of_work/constraints.rs:78-128 (+ Poseidon hasher.rs:17-40, hashing_utils.rs:15-877)

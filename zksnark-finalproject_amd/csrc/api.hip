@@ -588,6 +588,27 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
     return rc;
 }
 
+int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12], const uint64_t g2_gen[24],
+                uint64_t *a_query, uint8_t *a_inf, uint64_t *b_g1_query, uint8_t *b_g1_inf, uint64_t *b_g2_query, uint8_t *b_g2_inf,
+                uint64_t *h_query, uint64_t *l_query, uint8_t *l_inf,
+                uint64_t alpha_g1[12], uint64_t beta_g1[12], uint64_t beta_g2[24], uint64_t delta_g1[12], uint64_t delta_g2[24],
+                uint64_t gamma_g2[24], uint64_t *gamma_abc_g1) {
+    if (!trapdoor || !g1_gen || !g2_gen || !a_query || !b_g1_query || !b_g2_query || !h_query || !l_query || !alpha_g1 || !beta_g1 || !beta_g2 ||
+        !delta_g1 || !delta_g2 || !gamma_g2 || !gamma_abc_g1)
+        return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    if (!rc) return ZKG16_ERR_BAD_HANDLE;
+    Fr trap[5];
+    memcpy(trap, trapdoor, sizeof trap);
+    for (int i = 0; i < 5; i++)
+        if (trap[i].is_zero()) return ZKG16_ERR_BAD_ARG;
+    SetupOut o{a_query, b_g1_query, b_g2_query, h_query, l_query, gamma_abc_g1, a_inf, b_g1_inf, b_g2_inf, l_inf,
+               alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2};
+    setup_run(ctx, *rc, trap, g1_from_abi(g1_gen, 0), g2_from_abi(g2_gen, 0), o);
+    ZK_API_END(ctx)
+}
+
 // ------------------------------------------------------------------------------------------------ stages
 int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int coset) {
     if (!data) return ZKG16_ERR_BAD_ARG;

@@ -166,6 +166,15 @@ struct MsmPlan {
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
+void radix_sort_hi32(zkg16_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, unsigned key_bits, DevBuf &temp, const char *timer_name);
+// setup.hip: Groth16 key generation from a known trapdoor (discrete logs on device, then fixed-base batches)
+struct SetupOut {
+    uint64_t *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query, *gamma_abc_g1;
+    uint8_t *a_inf, *b_g1_inf, *b_g2_inf, *l_inf;
+    uint64_t *alpha_g1, *beta_g1, *beta_g2, *delta_g1, *delta_g2, *gamma_g2;
+};
+void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out);
+void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
 void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);

@@ -189,6 +189,12 @@ __global__ void fr_powers_kernel(Fr *out, Fr base, Fr scale, size_t n) {
     gst(out + i, fp_mul(fp_pow_u64(base, (uint64_t)i), scale));
 }
 
+void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, base, scale, n);
+    ZK_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static Fr fr_from_u64_host(uint64_t v) {
     Fr c = Fr::zero();

@@ -1,0 +1,163 @@
+// Groth16 circuit-specific setup from a caller-supplied trapdoor, on the device — the step the reference runs on every
+// request right before the hot path (`Groth16::<Bls12_381>::setup` at /root/reference/src/arkworks/backend/matrix_proof.rs:129,
+// `circuit_specific_setup` at fibbonaci_handler.rs:107 and prime_snark.rs:112-113; upstream ark-groth16 0.4
+// `generate_parameters_with_qap`, src/generator.rs — SURVEY.md A.7, scope row f-1).
+//   L_i(tau)                    one inverse NTT of (tau^j)_j                      [ntt.hip]
+//   u_k, v_k, w_k               column sums of A, B, C weighted by L  (CSR -> column order by a radix sort of (col, entry))
+//   query scalars               a = u, b = v, l = (beta u + alpha v + w)/delta, gamma_abc = (...)/gamma, h_i = tau^i Z(tau)/delta
+//   query points                fixed-base batch multiplication [scalar] g      [msm.hip fixed_base_*]
+// The caller draws tau, alpha, beta, gamma, delta and the two generators exactly as upstream does (from its rng).
+#include "common.hpp"
+
+namespace zk {
+
+__device__ __forceinline__ Fr ld_fr(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
+}
+__device__ __forceinline__ void st_fr(Fr *p, const Fr &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// keys[e] = col[e] << 32 | e, and the row of every CSR entry
+__global__ void __launch_bounds__(256) setup_expand_kernel(const uint64_t *row_ptr, const uint32_t *col, size_t nrows, uint64_t *keys, uint32_t *rowid) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        keys[e] = ((uint64_t)col[e] << 32) | (uint64_t)(uint32_t)e;
+        rowid[e] = (uint32_t)r;
+    }
+}
+// first sorted position whose column is >= k, k = 0..ncols
+__global__ void __launch_bounds__(256) setup_col_offsets_kernel(const uint2 *sorted, size_t nnz, uint32_t *offsets, size_t ncols) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > ncols) return;
+    size_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (sorted[mid].y < (uint32_t)k) lo = mid + 1; else hi = mid;
+    }
+    offsets[k] = (uint32_t)lo;
+}
+// out[k] = sum over the entries of column k of coeff[e] * L[row[e]]   (+ L[nc + k] for k < num_instance when add_inputs)
+__global__ void __launch_bounds__(256) setup_col_sum_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
+                                                            const Fr *L, size_t ncols, size_t nc, size_t num_instance, int add_inputs, Fr *out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    Fr acc = Fr::zero();
+    for (uint32_t p = offsets[k]; p < offsets[k + 1]; p++) {
+        const uint32_t e = sorted[p].x;
+        acc = fp_add(acc, fp_mul(ld_fr(coeff + e), ld_fr(L + rowid[e])));
+    }
+    if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
+    st_fr(out + k, acc);
+}
+// lg[k] = (beta u_k + alpha v_k + w_k) * (k < num_instance ? gamma^-1 : delta^-1)
+__global__ void __launch_bounds__(256) setup_lg_kernel(const Fr *u, const Fr *v, const Fr *w, Fr alpha, Fr beta, Fr ginv, Fr dinv, size_t ncols,
+                                                       size_t num_instance, Fr *lg) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    Fr x = fp_add(fp_add(fp_mul(beta, ld_fr(u + k)), fp_mul(alpha, ld_fr(v + k))), ld_fr(w + k));
+    st_fr(lg + k, fp_mul(x, k < num_instance ? ginv : dinv));
+}
+
+static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf) {
+    if (!n) return;
+    canon.ensure(n * sizeof(Fr));
+    pts.ensure(n * sizeof(G1Affine));
+    fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
+    fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, pts.as<G1Affine>());
+    ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (inf) {
+        const G1Affine *o = reinterpret_cast<const G1Affine *>(out);
+        for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
+    }
+}
+static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf) {
+    if (!n) return;
+    canon.ensure(n * sizeof(Fr));
+    pts.ensure(n * sizeof(G2Affine));
+    fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
+    fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, pts.as<G2Affine>());
+    ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (inf) {
+        const G2Affine *o = reinterpret_cast<const G2Affine *>(out);
+        for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
+    }
+}
+
+void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out) {
+    const Fr &tau = trap[0], &alpha = trap[1], &beta = trap[2], &gamma = trap[3], &delta = trap[4];
+    const size_t N = (size_t)1 << m.log_n, nc = m.num_constraints, ni = m.num_instance, nv = m.num_variables;
+    Fr zt = tau;
+    for (int i = 0; i < m.log_n; i++) zt = fp_sqr(zt);
+    zt = fp_sub(zt, Fr::one());                                  // Z(tau) = tau^N - 1
+    if (zt.is_zero()) throw HipError{hipErrorInvalidValue, "setup: tau lies in the evaluation domain", __FILE__, __LINE__};
+    const Fr dinv = fp_inv(delta), ginv = fp_inv(gamma);
+
+    // L = ifft((tau^j)_j)
+    DevBuf L(N * sizeof(Fr)), tmp(N * sizeof(Fr));
+    fr_powers_run(ctx, L.as<Fr>(), tau, Fr::one(), N);
+    ntt_run(ctx, L.as<Fr>(), tmp.as<Fr>(), m.log_n, true, false);
+
+    // u, v, w: per-matrix column sums
+    DevBuf uvw[3];
+    DevBuf keys, sorted, rowid, coloff, sort_temp;
+    unsigned key_bits = 1;
+    while (((size_t)1 << key_bits) <= nv) key_bits++;
+    for (int k = 0; k < 3; k++) {
+        uvw[k].alloc(nv * sizeof(Fr));
+        const size_t nnz = m.nnz[k];
+        keys.ensure((nnz ? nnz : 1) * sizeof(uint64_t));
+        sorted.ensure((nnz ? nnz : 1) * sizeof(uint64_t));
+        rowid.ensure((nnz ? nnz : 1) * sizeof(uint32_t));
+        coloff.ensure((nv + 1) * sizeof(uint32_t));
+        if (nnz) {
+            hipLaunchKernelGGL(setup_expand_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, m.rp[k].as<uint64_t>(),
+                               m.col[k].as<uint32_t>(), nc, keys.as<uint64_t>(), rowid.as<uint32_t>());
+            radix_sort_hi32(ctx, keys.as<uint64_t>(), sorted.as<uint64_t>(), nnz, key_bits, sort_temp, "setup_radix_sort");
+        }
+        hipLaunchKernelGGL(setup_col_offsets_kernel, dim3((unsigned)((nv + 1 + 255) / 256)), dim3(256), 0, ctx->stream, sorted.as<uint2>(), nnz,
+                           coloff.as<uint32_t>(), nv);
+        hipLaunchKernelGGL(setup_col_sum_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, sorted.as<uint2>(),
+                           coloff.as<uint32_t>(), rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nv, nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>());
+        ZK_HIP(hipGetLastError());
+    }
+    DevBuf lg(nv * sizeof(Fr));
+    hipLaunchKernelGGL(setup_lg_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, uvw[0].as<Fr>(), uvw[1].as<Fr>(),
+                       uvw[2].as<Fr>(), alpha, beta, ginv, dinv, nv, ni, lg.as<Fr>());
+    ZK_HIP(hipGetLastError());
+    // h_i = tau^i * Z(tau) / delta, i < N - 1   (reuses L's storage)
+    fr_powers_run(ctx, L.as<Fr>(), tau, fp_mul(zt, dinv), N - 1);
+
+    DevBuf canon, pts;
+    points_g1(ctx, g1, uvw[0].as<Fr>(), nv, canon, pts, out.a_query, out.a_inf);
+    points_g1(ctx, g1, uvw[1].as<Fr>(), nv, canon, pts, out.b_g1_query, out.b_g1_inf);
+    points_g2(ctx, g2, uvw[1].as<Fr>(), nv, canon, pts, out.b_g2_query, out.b_g2_inf);
+    points_g1(ctx, g1, L.as<Fr>(), N - 1, canon, pts, out.h_query, nullptr);
+    points_g1(ctx, g1, lg.as<Fr>() + ni, nv - ni, canon, pts, out.l_query, out.l_inf);
+    points_g1(ctx, g1, lg.as<Fr>(), ni, canon, pts, out.gamma_abc_g1, nullptr);
+    // alpha, beta, delta (G1) ; beta, delta, gamma (G2)
+    Fr singles[4] = {alpha, beta, delta, gamma};
+    DevBuf d_s(4 * sizeof(Fr));
+    ZK_HIP(hipMemcpyAsync(d_s.p, singles, sizeof singles, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t o1[4 * 12], o2[4 * 24];
+    points_g1(ctx, g1, d_s.as<Fr>(), 4, canon, pts, o1, nullptr);
+    points_g2(ctx, g2, d_s.as<Fr>(), 4, canon, pts, o2, nullptr);
+    memcpy(out.alpha_g1, o1, 96);
+    memcpy(out.beta_g1, o1 + 12, 96);
+    memcpy(out.delta_g1, o1 + 24, 96);
+    memcpy(out.beta_g2, o2 + 24, 192);
+    memcpy(out.delta_g2, o2 + 48, 192);
+    memcpy(out.gamma_g2, o2 + 72, 192);
+}
+
+}  // namespace zk

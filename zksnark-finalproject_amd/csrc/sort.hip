@@ -15,17 +15,20 @@
 
 namespace zk {
 
-void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits) {
+// sort 64-bit keys by their bits [32, 32 + key_bits)
+void radix_sort_hi32(zkg16_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, unsigned key_bits, DevBuf &temp, const char *timer_name) {
     if (count == 0) return;
-    const uint64_t *in = ws.keys.as<uint64_t>();
-    uint64_t *out = ws.entries.as<uint64_t>();
     size_t temp_bytes = 0;
     hipError_t e = rocprim::radix_sort_keys(nullptr, temp_bytes, in, out, count, 32u, 32u + key_bits, ctx->stream);
     if (e != hipSuccess) throw HipError{e, "rocprim::radix_sort_keys(size query)", __FILE__, __LINE__};
-    ws.sort_temp.ensure(temp_bytes);
-    ScopedKernelTimer kt(ctx, "msm_radix_sort", (double)count, ctx->stream);
-    e = rocprim::radix_sort_keys(ws.sort_temp.p, temp_bytes, in, out, count, 32u, 32u + key_bits, ctx->stream);
+    temp.ensure(temp_bytes);
+    ScopedKernelTimer kt(ctx, timer_name, (double)count, ctx->stream);
+    e = rocprim::radix_sort_keys(temp.p, temp_bytes, in, out, count, 32u, 32u + key_bits, ctx->stream);
     if (e != hipSuccess) throw HipError{e, "rocprim::radix_sort_keys", __FILE__, __LINE__};
+}
+
+void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits) {
+    radix_sort_hi32(ctx, ws.keys.as<uint64_t>(), ws.entries.as<uint64_t>(), count, key_bits, ws.sort_temp, "msm_radix_sort");
 }
 
 }  // namespace zk

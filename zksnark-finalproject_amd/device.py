@@ -210,3 +210,28 @@ def combine_partials(alpha_g1, beta_g1, beta_g2, r, s, partials, partial_inf):
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     return proof, inf
+
+
+def _setup(self, r1cs_h, num_instance, num_vars, domain, trapdoor_mont, g1_gen, g2_gen):
+    """Groth16 setup on the device from a known trapdoor (zkg16_setup) -> (pk dict for pk_load, vk dict)."""
+    nw = num_vars - num_instance
+    pk = dict(a_query=np.zeros((num_vars, 12), np.uint64), a_inf=np.zeros(num_vars, np.uint8),
+              b_g1_query=np.zeros((num_vars, 12), np.uint64), b_g1_inf=np.zeros(num_vars, np.uint8),
+              b_g2_query=np.zeros((num_vars, 24), np.uint64), b_g2_inf=np.zeros(num_vars, np.uint8),
+              h_query=np.zeros((max(domain - 1, 1), 12), np.uint64), l_query=np.zeros((max(nw, 1), 12), np.uint64),
+              l_inf=np.zeros(max(nw, 1), np.uint8),
+              alpha_g1=np.zeros(12, np.uint64), beta_g1=np.zeros(12, np.uint64), beta_g2=np.zeros(24, np.uint64),
+              delta_g1=np.zeros(12, np.uint64), delta_g2=np.zeros(24, np.uint64))
+    vk = dict(gamma_g2=np.zeros(24, np.uint64), gamma_abc_g1=np.zeros((num_instance, 12), np.uint64))
+    self._check(self.lib.zkg16_setup(
+        self.ctx, r1cs_h, _u64(trapdoor_mont).reshape(-1), _u64(g1_gen), _u64(g2_gen),
+        pk["a_query"], _ptr(pk["a_inf"]), pk["b_g1_query"], _ptr(pk["b_g1_inf"]), pk["b_g2_query"], _ptr(pk["b_g2_inf"]),
+        _ptr(pk["h_query"]), _ptr(pk["l_query"]), _ptr(pk["l_inf"]),
+        pk["alpha_g1"], pk["beta_g1"], pk["beta_g2"], pk["delta_g1"], pk["delta_g2"], vk["gamma_g2"], vk["gamma_abc_g1"]))
+    pk["h_query"] = pk["h_query"][:domain - 1]
+    pk["l_query"], pk["l_inf"] = pk["l_query"][:nw], pk["l_inf"][:nw]
+    vk.update(alpha_g1=pk["alpha_g1"], beta_g2=pk["beta_g2"], delta_g2=pk["delta_g2"])
+    return pk, vk
+
+
+Device.setup = _setup
