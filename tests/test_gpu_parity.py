@@ -321,3 +321,18 @@ def test_setup_on_device_vs_oracle(dev, oracle, kind):
     assert np.array_equal(proof[36:], oracle.point_mul("g1", meta["g1"], fr_canon(cc))[0])
     for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
         f(hnd)
+
+
+def test_handler_mirrors_end_to_end(dev, oracle):
+    """prove_matrix / prove_fibonacci (handlers.py: synthesize -> device setup -> device prove -> wire encoding): the proof
+    the handler returns decodes to exactly the oracle's proof for the same key, r, s."""
+    from zksnark_finalproject_amd import handlers, wire
+    for res in (handlers.prove_matrix(dev, 4, np.ones((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64)),
+                handlers.prove_fibonacci(dev, 0, 1, 100)):
+        d, circ = res["_detail"], res["_circuit"]
+        proof, inf = wire.decode_proof(res["proof"])
+        assert len(wire.proof_serialize_compressed(proof, inf)) == 192
+        eproof, einf = oracle.prove(d["pk"], d["r"], d["s"], circ.r1cs, circ.z)
+        assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
+        assert res["proving_time"] > 0 and res["setup_time"] > 0
+    assert res["num_constraints"] == 101

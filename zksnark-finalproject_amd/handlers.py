@@ -1,0 +1,64 @@
+"""In-process mirrors of the reference's request handlers around the hot path (the callers of `Groth16::prove`):
+    prove_matrix     src/arkworks/backend/matrix_proof.rs:94-166   (POST /api/matrix_prove/prove)
+    prove_fibonacci  src/arkworks/backend/fibbonaci_handler.rs:98-145
+Same steps, same response fields: synthesize the circuit (host C++ mirror), per-request Groth16 setup (on the device,
+zkg16_setup), prove (zkg16_prove_resident), encode (wire.py).  The reference's HTTP layer (actix-web) is out of scope; the
+trapdoor and r, s come from Python's PRNG rather than arkworks' StdRng stream, so proofs are valid Groth16 proofs for the
+same statement but not the byte string the Rust server would emit for its seed."""
+import random
+import time
+
+import numpy as np
+
+from . import wire
+from .circuits import fibonacci_circuit, matrix_circuit
+from .workloads import R_MOD, g1_generator, g2_generator
+
+
+def _fr_mont(x):
+    v = (x << 256) % R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def _setup_and_prove(dev, circ, rng):
+    trap = np.stack([_fr_mont(rng.randrange(1, R_MOD)) for _ in range(5)])
+    # arkworks draws random generators; any subgroup generator gives a valid key: [k]G for random k
+    k = np.stack([np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)])
+    g1 = dev.fixed_base("g1", g1_generator(), k)[0][0]
+    g2 = dev.fixed_base("g2", g2_generator(), k)[0][0]
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    t0 = time.perf_counter()
+    pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)
+    ph = dev.pk_load(pk, circ.num_instance)
+    setup_time = time.perf_counter() - t0
+    wh = dev.witness_load(circ.z)
+    r, s = _fr_mont(rng.randrange(R_MOD)), _fr_mont(rng.randrange(R_MOD))
+    t0 = time.perf_counter()
+    proof, inf = dev.prove_resident(ph, rh, wh, r, s)
+    proving_time = time.perf_counter() - t0
+    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(h)
+    return dict(proof=proof, inf=inf, vk=vk, pk=pk, setup_time=setup_time, proving_time=proving_time, r=r, s=s)
+
+
+def prove_matrix(dev, size, matrix_a, matrix_b, seed=0):
+    """-> the reference's ProveOutput fields (matrix_proof.rs:80-91)."""
+    a = np.asarray(matrix_a, dtype=np.uint64).reshape(size, size)
+    b = np.asarray(matrix_b, dtype=np.uint64).reshape(size, size)
+    circ = matrix_circuit(a, b)
+    out = _setup_and_prove(dev, circ, random.Random(seed))
+    ha, hb, hc = circ.public_inputs
+    return dict(hash_a=wire.encode_hash(ha), hash_b=wire.encode_hash(hb), hash_c=wire.encode_hash(hc),
+                setup_time=out["setup_time"], proving_time=out["proving_time"],
+                # the reference counts matrix_mul twice (outer cs + circuit: matrix_proof.rs:108,150,160)
+                num_constraints=circ.num_constraints + 2 * size ** 3, num_constraints_circuit=circ.num_constraints,
+                num_variables=circ.num_instance, proof=wire.encode_proof(out["proof"], out["inf"]), _detail=out, _circuit=circ)
+
+
+def prove_fibonacci(dev, a, b, num_of_rounds, seed=42):
+    """-> the reference's OutputDataFib-like fields (fibbonaci_handler.rs:84-90)."""
+    circ = fibonacci_circuit(a, b, num_of_rounds)
+    out = _setup_and_prove(dev, circ, random.Random(seed))
+    return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
+                num_constraints=circ.num_constraints, num_variables=circ.num_instance,
+                fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], _detail=out, _circuit=circ)

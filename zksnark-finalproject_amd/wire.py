@@ -1,0 +1,143 @@
+"""Wire formats either side of the hot path (scope row f-2), as the reference ships them over its JSON API
+(src/arkworks/matrix_proof_of_work/io.rs:45-88, backend/matrix_proof.rs:116-120,196-198):
+  * Proof  -> `serialize_compressed` (ark-bls12-381 0.4: zcash-style BLS12-381 encoding, A 48 B | B 96 B | C 48 B) -> base64 STANDARD
+  * Fr hash -> 32-byte little-endian canonical -> base64; decoded with from_le_bytes_mod_order
+Point encoding: big-endian x; top three bits of the first byte = compressed (1), infinity, y-is-lexicographically-largest;
+G2 is x.c1 || x.c0 and compares y by (c1, c0).  Pure Python integers (six field elements per proof: not a hot path)."""
+import base64
+
+import numpy as np
+
+Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+_RQ_INV = pow(1 << 384, -1, Q)
+_RR_INV = pow(1 << 256, -1, R)
+
+
+def _int(limbs):
+    return sum(int(v) << (64 * i) for i, v in enumerate(limbs))
+
+
+def _limbs(x, n):
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+def _fq(limbs):            # Montgomery limbs -> canonical int
+    return _int(limbs) * _RQ_INV % Q
+
+
+def _fq_mont(x):
+    return _limbs((x << 384) % Q, 6)
+
+
+def g1_compress(p12, inf):
+    if inf:
+        return bytes([0xC0]) + bytes(47)
+    x, y = _fq(p12[:6]), _fq(p12[6:])
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if y > (Q - y) % Q else 0)
+    return bytes(b)
+
+
+def g2_compress(p24, inf):
+    if inf:
+        return bytes([0xC0]) + bytes(95)
+    x0, x1, y0, y1 = (_fq(p24[6 * i:6 * i + 6]) for i in range(4))
+    ny0, ny1 = (-y0) % Q, (-y1) % Q
+    largest = (y1, y0) > (ny1, ny0)
+    b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if largest else 0)
+    return bytes(b)
+
+
+def _sqrt_fq(a):
+    r = pow(a, (Q + 1) // 4, Q)            # q = 3 mod 4
+    return r if r * r % Q == a % Q else None
+
+
+def _sqrt_fq2(a0, a1):
+    """sqrt in Fq[u]/(u^2+1) (complex method); returns (c0, c1) or None."""
+    if a1 == 0:
+        r = _sqrt_fq(a0)
+        if r is not None:
+            return r, 0
+        r = _sqrt_fq((-a0) % Q)
+        return (0, r) if r is not None else None
+    n = _sqrt_fq((a0 * a0 + a1 * a1) % Q)
+    if n is None:
+        return None
+    inv2 = pow(2, -1, Q)
+    for cand in ((a0 + n) * inv2 % Q, (a0 - n) * inv2 % Q):
+        c0 = _sqrt_fq(cand)
+        if c0:
+            c1 = a1 * pow(2 * c0, -1, Q) % Q
+            if (c0 * c0 - c1 * c1) % Q == a0 % Q:
+                return c0, c1
+    return None
+
+
+def g1_decompress(b):
+    assert len(b) == 48 and b[0] & 0x80, "not a compressed G1 point"
+    if b[0] & 0x40:
+        return np.zeros(12, dtype=np.uint64), 1
+    x = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:], "big")
+    y = _sqrt_fq((x * x * x + 4) % Q)
+    if y is None:
+        raise ValueError("x not on curve")
+    if (y > (Q - y) % Q) != bool(b[0] & 0x20):
+        y = (Q - y) % Q
+    return np.concatenate([_fq_mont(x), _fq_mont(y)]), 0
+
+
+def g2_decompress(b):
+    assert len(b) == 96 and b[0] & 0x80, "not a compressed G2 point"
+    if b[0] & 0x40:
+        return np.zeros(24, dtype=np.uint64), 1
+    x1 = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:48], "big")
+    x0 = int.from_bytes(b[48:], "big")
+    # x^3 + 4(1 + u)
+    a0 = (x0 * x0 - x1 * x1) % Q
+    a1 = 2 * x0 * x1 % Q
+    c0 = (a0 * x0 - a1 * x1 + 4) % Q
+    c1 = (a0 * x1 + a1 * x0 + 4) % Q
+    s = _sqrt_fq2(c0, c1)
+    if s is None:
+        raise ValueError("x not on curve")
+    y0, y1 = s
+    if ((y1, y0) > ((-y1) % Q, (-y0) % Q)) != bool(b[0] & 0x20):
+        y0, y1 = (-y0) % Q, (-y1) % Q
+    return np.concatenate([_fq_mont(x0), _fq_mont(x1), _fq_mont(y0), _fq_mont(y1)]), 0
+
+
+def proof_serialize_compressed(proof48, inf3):
+    """(A | B | C affine Montgomery limbs, infinity flags) -> 192 bytes (io.rs:45-51 before base64)."""
+    p = np.asarray(proof48, dtype=np.uint64)
+    return g1_compress(p[:12], inf3[0]) + g2_compress(p[12:36], inf3[1]) + g1_compress(p[36:], inf3[2])
+
+
+def proof_deserialize_compressed(b):
+    assert len(b) == 192
+    a, ia = g1_decompress(b[:48])
+    bb, ib = g2_decompress(b[48:144])
+    c, ic = g1_decompress(b[144:])
+    return np.concatenate([a, bb, c]), np.array([ia, ib, ic], dtype=np.uint8)
+
+
+def encode_proof(proof48, inf3):
+    return base64.standard_b64encode(proof_serialize_compressed(proof48, inf3)).decode()
+
+
+def decode_proof(s):
+    return proof_deserialize_compressed(base64.standard_b64decode(s))
+
+
+def encode_hash(fr_mont_limbs):
+    """Fr (Montgomery limbs) -> into_bigint().to_bytes_le() -> base64 (matrix_proof.rs:116-120)."""
+    v = _int(fr_mont_limbs) * _RR_INV % R
+    return base64.standard_b64encode(v.to_bytes(32, "little")).decode()
+
+
+def decode_hash(s):
+    """base64 -> Fr::from_le_bytes_mod_order (matrix_proof.rs:196-198) -> Montgomery limbs"""
+    v = int.from_bytes(base64.standard_b64decode(s), "little") % R
+    return _limbs((v << 256) % R, 4)
