@@ -336,3 +336,24 @@ def test_handler_mirrors_end_to_end(dev, oracle):
         assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
         assert res["proving_time"] > 0 and res["setup_time"] > 0
     assert res["num_constraints"] == 101
+
+
+def test_setup_prove_verify_with_pairings(dev):
+    """setup (device) -> prove (device) -> verify (pure-Python pairings) == true, and false for a wrong public input:
+    the reference's own acceptance test (constraints.rs:231-272, fibbonaci.rs:192-232) end to end, with NO oracle involved."""
+    import pyref_pairing as PP
+    from zksnark_finalproject_amd import handlers, wire
+    to1 = lambda l: P.g1_from_limbs([int(v) for v in l])
+    to2 = lambda l: P.g2_from_limbs([int(v) for v in l])
+    for res in (handlers.prove_matrix(dev, 3, np.ones((3, 3), dtype=np.uint64), 2 * np.ones((3, 3), dtype=np.uint64), seed=5),
+                handlers.prove_fibonacci(dev, 0, 1, 50, seed=6)):
+        d, circ = res["_detail"], res["_circuit"]
+        vk = dict(alpha_g1=to1(d["vk"]["alpha_g1"]), beta_g2=to2(d["vk"]["beta_g2"]), gamma_g2=to2(d["vk"]["gamma_g2"]),
+                  delta_g2=to2(d["vk"]["delta_g2"]), gamma_abc_g1=[to1(g) for g in d["vk"]["gamma_abc_g1"]])
+        proof, inf = wire.decode_proof(res["proof"])            # through the wire format
+        pr = (to1(proof[:12]), to2(proof[12:36]), to1(proof[36:]))
+        pub = fr_from_mont_vec(circ.public_inputs)
+        assert PP.groth16_verify(vk, pub, pr)
+        bad = list(pub)
+        bad[-1] = (bad[-1] + 1) % P.R_MOD
+        assert not PP.groth16_verify(vk, bad, pr)

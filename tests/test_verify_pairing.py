@@ -1,0 +1,48 @@
+"""The reference's own test strategy (setup -> prove -> assert verify == true; e.g.
+src/arkworks/matrix_proof_of_work/constraints.rs:231-272, constraints/fibbonaci.rs:192-232) with a pure-Python pairing
+verifier (tests/golden/pyref_pairing.py): the golden Groth16 fixtures and the oracle's proofs satisfy the real
+verification equation e(A,B) = e(alpha,beta) e(sum z_i gamma_abc_i, gamma) e(C,delta), and a wrong public input fails."""
+import numpy as np
+import pytest
+
+import pyref as P
+import pyref_pairing as PP
+from helpers import *
+
+
+def _vk_from_case(case):
+    g1s, g2s, t = H(case["g1_scalar"]), H(case["g2_scalar"]), {k: H(v) for k, v in case["trapdoor"].items()}
+    return dict(alpha_g1=P.g1_mul(t["alpha"] * g1s), beta_g2=P.g2_mul(t["beta"] * g2s), gamma_g2=P.g2_mul(t["gamma"] * g2s),
+                delta_g2=P.g2_mul(t["delta"] * g2s), gamma_abc_g1=[P.g1_mul(H(k) * g1s) for k in case["logs"]["gamma_abc"]])
+
+
+def _pt1(j):
+    return None if j is None else (P.Fq1(H(j[0])), P.Fq1(H(j[1])))
+
+
+def _pt2(j):
+    return None if j is None else (P.Fq2(H(j[0]), H(j[1])), P.Fq2(H(j[2]), H(j[3])))
+
+
+def test_golden_proofs_verify_with_pairings(oracle):
+    for case in load("groth16_kat.json"):
+        vk = _vk_from_case(case)
+        pub = [H(v) for v in case["z"][1:case["num_inputs"]]]
+        proof = (_pt1(case["proof"]["a"]), _pt2(case["proof"]["b"]), _pt1(case["proof"]["c"]))
+        assert PP.groth16_verify(vk, pub, proof), case["name"]
+        bad = list(pub)
+        bad[0] = (bad[0] + 1) % P.R_MOD
+        assert not PP.groth16_verify(vk, bad, proof), case["name"]
+        # the oracle's proof (real MSMs / NTTs) for the same key verifies too
+        r1cs, _ = r1cs_from_case(case)
+        op, oinf = oracle.prove(pk_from_case(case), fr_mont(H(case["r"])), fr_mont(H(case["s"])), r1cs, fr_mont_vec([H(v) for v in case["z"]]))
+        oproof = (g1_from_limbs(op[:12]), g2_from_limbs(op[12:36]), g1_from_limbs(op[36:]))
+        assert PP.groth16_verify(vk, pub, oproof)
+
+
+def g1_from_limbs(l):
+    return P.g1_from_limbs([int(v) for v in l])
+
+
+def g2_from_limbs(l):
+    return P.g2_from_limbs([int(v) for v in l])
