@@ -197,6 +197,10 @@ def main():
         alg_bytes = 128.0 * terms_per_launch
         avg_ms = acc["ms"] / max(acc["launches"], 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of one msm_accumulate_g1 launch from rocprofv3 PMC passes of this same command (profiles/
+        # rocprofv3_pmc_r1_fetch_write.txt: FETCH_SIZE + WRITE_SIZE, calibrated on ntt_pass_cols: no 2x for 112-B gathers);
+        # only known for the default workload on one GPU
+        traffic = 1.05e9 if (world == 1 and args.matrix_n == 32) else None
         out = {
             "metric": "groth16_proofs_per_sec", "value": args.steps / dt, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -210,11 +214,12 @@ def main():
             "constraints_per_sec": shp["nc"] * args.steps / dt,
             "stage_ms_last_proof": stages,
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_g1", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "bucket_additions_per_launch": acc["units"] / max(acc["launches"], 1),
-                         "note": "integer-ALU bound by construction (~10 381-bit Montgomery products per 128 algorithmic bytes); "
-                                 "g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
+                         "terms_per_launch": acc["units"] / max(acc["launches"], 1),
+                         "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (~4,700 VALU "
+                                 "instructions) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command "
+                                 "(bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, shp["nc"], min(os.cpu_count() or 1, 16))

@@ -44,10 +44,9 @@ typedef uint32_t VarId;
 const VarId WIT = 0x80000000u;
 
 struct Term { VarId v; Fr c; };
-static bool term_less(const Term &a, const Term &b) { return a.v < b.v; }
 
-// An FpVar: a linear combination over variables (sorted by id) with its value; an empty LC is the constant... no:
-// constants are LCs over the One variable only (`is_const`), mirroring FpVar::Constant.
+// An FpVar: a linear combination over variables (sorted by id) together with its value.  Constants are LCs over the
+// One variable only (`is_const`), mirroring FpVar::Constant.
 struct Lc {
     std::vector<Term> t;
     Fr val = Fr::zero();

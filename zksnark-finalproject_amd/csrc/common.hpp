@@ -75,8 +75,8 @@ struct PkDev {              // proving key shard resident in HBM (affine AoS; (0
     DevBuf a, b1, l;                                 // G1AffineU[z_hi - z_lo + 3]  (three trailing slots: r, s, -rs terms)
     DevBuf b2;                                       // G2AffineU[z_hi - z_lo + 3]
     DevBuf h;                                        // G1AffineU[h_hi - h_lo]
-    G1Affine a0, b1_0, alpha_g1, beta_g1, delta_g1;  // host copies for the tail
-    G2Affine b2_0, beta_g2, delta_g2;
+    G1Affine alpha_g1, beta_g1, delta_g1;            // host copies for the tail
+    G2Affine beta_g2, delta_g2;
     int shard_index = 0, shard_count = 1;
 };
 
@@ -99,7 +99,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, counts, offsets, cursors, seg_meta, seg_head, seg_tail, buckets, lvl_a, lvl_b, lvl_c, lvl_d, scalars, long_list, sort_temp;
+    DevBuf keys, entries, offsets, seg_meta, seg_head, seg_tail, scalars, long_list, sort_temp;
 };
 
 }  // namespace zk
@@ -119,7 +119,6 @@ struct zkg16_ctx {
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
     zk::DevBuf red_a, red_b, red_c;                   // reduction scratch (aux stream is in-order, so shared)
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
-    zk::DevBuf hscal;                                 // canonical h
     float timings[16] = {0};
     bool kernel_timing = false;
     std::map<std::string, zk::KernelStat> kstats;
