@@ -17,8 +17,6 @@ if len(sys.argv) > 2:
     dev.set_option("window_bits", int(sys.argv[2]))
 if len(sys.argv) > 3:
     dev.set_option("reduce_chunk", int(sys.argv[3]))
-if len(sys.argv) > 4:
-    dev.set_option("g2_last", int(sys.argv[4]))
 r1cs, z, shp = matmul_like_r1cs(n)
 pk = bench.make_key(dev, r1cs, shp, seed=1)
 ph, rh, wh = dev.pk_load(pk, 4), dev.r1cs_load(r1cs, shp["num_vars"]), dev.witness_load(z)

@@ -27,6 +27,7 @@ void kernel_timer_resolve(zkg16_ctx *ctx) {
     if (ctx->pending_events.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamSynchronize(ctx->wm_stream);
     for (auto &p : ctx->pending_events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -147,75 +148,82 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     if (wit.n != m_total || pk.m_total != m_total) throw HipError{hipErrorInvalidValue, "prove: assignment / key length mismatch", __FILE__, __LINE__};
     const size_t N = (size_t)1 << rc.log_n;
     if (pk.n_h_total != N - 1) throw HipError{hipErrorInvalidValue, "prove: h_query length != N-1", __FILE__, __LINE__};
-    hipEvent_t ev[8];
+    hipEvent_t ev[5];                     // 0-1: z-side sort (main stream), 2-4: witness map / h-side sort (aux stream)
     for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
     const double t0 = now_ms();
-    ZK_HIP(hipEventRecord(ev[0], ctx->stream));
 
-    // ---- R1CS -> QAP: h (Montgomery), a3-a5 of SURVEY.md 8a
-    Fr *h = nullptr;
-    {
-        // SpMV is timed apart from the NTTs
-        const size_t n = N;
-        for (int i = 0; i < 4; i++) ctx->poly[i].ensure(n * sizeof(Fr));
-    }
-    witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
-    ZK_HIP(hipEventRecord(ev[1], ctx->stream));
-
-    // ---- scalar vectors in canonical form
+    // ---- main stream: the z-side scalar vector (z-slice || r, s, -rs) -> canonical -> digits -> sort.  It does not depend
+    // on the witness map, so the G2 accumulation can start while h is still being computed on the aux stream.
     const size_t nz = pk.z_hi - pk.z_lo;
     const size_t nzs = nz + 3;                                 // + r, s, -rs slots
     const size_t nh = pk.h_hi - pk.h_lo;
     ctx->ws_z.scalars.ensure(nzs * sizeof(Fr));
+    ctx->ws_z.stage.ensure(nzs * sizeof(Fr));
     ctx->ws_h.scalars.ensure((nh ? nh : 1) * sizeof(Fr));
+    for (int i = 0; i < 4; i++) ctx->poly[i].ensure(N * sizeof(Fr));
     Fr *zs = ctx->ws_z.scalars.as<Fr>();
     Fr *hs = ctx->ws_h.scalars.as<Fr>();
+    MsmPlan plan_z, plan_h;
+    ZK_HIP(hipEventRecord(ev[0], ctx->stream));
     {
-        Fr extra[3];
+        if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
+        Fr *extra = reinterpret_cast<Fr *>(ctx->extra_host);
         const bool first = pk.shard_index == 0;               // the r/s/-rs terms are added by shard 0 only
         extra[0] = first ? r : Fr::zero();
         extra[1] = first ? s : Fr::zero();
         extra[2] = first ? fp_neg(fp_mul(r, s)) : Fr::zero();
-        // stage z-slice || extras (Montgomery) in poly[1] (free after the witness map), then convert
-        Fr *stage = ctx->poly[1].as<Fr>();
-        ctx->poly[1].ensure(nzs * sizeof(Fr));
-        stage = ctx->poly[1].as<Fr>();
+        Fr *stage = ctx->ws_z.stage.as<Fr>();
         if (nz) ZK_HIP(hipMemcpyAsync(stage, wit.z.as<Fr>() + pk.z_lo, nz * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(stage + nz, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));            // `extra` is a stack buffer
+        ZK_HIP(hipMemcpyAsync(stage + nz, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));   // pinned; reused only after this proof
         fr_from_mont_run(ctx, stage, zs, nzs);
-        if (nh) fr_from_mont_run(ctx, h + pk.h_lo, hs, nh);
+        msm_plan_build(ctx, ctx->ws_z, zs, nzs, plan_z);
     }
-    MsmPlan plan_z, plan_h;
-    msm_plan_build(ctx, ctx->ws_z, zs, nzs, plan_z);
-    msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
-    ZK_HIP(hipEventRecord(ev[2], ctx->stream));
+    ZK_HIP(hipEventRecord(ev[1], ctx->stream));
 
-    // queue all five MSMs (the G2 one first: its long reduction then hides behind the four G1 accumulations), then
-    // collect: each MSM's host Horner overlaps the device work still queued behind it
-    if (!ctx->opt_g2_last) msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
-    msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
+    // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
+    // z-side work (measured in one process, n = 32: 18.15 vs 18.58 ms in order; n = 12: 10.05 vs 11.16 ms)
+    const bool wm_concurrent = ctx->opt_wm_concurrent != 0;
+    if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);      // every launch helper targets ctx->stream
+    try {
+        ZK_HIP(hipEventRecord(ev[2], ctx->stream));
+        Fr *h = nullptr;
+        witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
+        ZK_HIP(hipEventRecord(ev[3], ctx->stream));
+        if (nh) fr_from_mont_run(ctx, h + pk.h_lo, hs, nh);
+        msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
+        ZK_HIP(hipEventRecord(ev[4], ctx->stream));
+    } catch (...) {
+        if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
+        throw;
+    }
+    if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
+
+    // ---- queue the five MSMs: accumulations on the main stream (G2 first: its long reduction then hides behind the G1
+    // accumulations; H last: it is the only one that waits for the witness map), reductions on the aux stream; then collect —
+    // each MSM's host Horner overlaps the device work still queued behind it
+    msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), ctx->slots[4]);
-    if (ctx->opt_g2_last) msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+    ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
+    msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
     double tprev = now_ms();
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
-    if (!ctx->opt_g2_last) { out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7); }
-    out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
+    out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
     out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
     out.a = msm_g1_collect(ctx, ctx->slots[3]); lap(5);
     out.b1 = msm_g1_collect(ctx, ctx->slots[4]); lap(6);
-    if (ctx->opt_g2_last) { out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7); }
-    ZK_HIP(hipEventSynchronize(ev[2]));
+    out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
     float ms;
-    // [1] witness map, [2] digits+sort (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2 (collected in
-    // the order B2, H, L, A, B1 — the first gap contains most of the device time)
+    // [1] witness map, [2] digits+sort of both vectors (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2
+    // (collected in the order B2, L, A, B1, H — the first gap contains most of the device time)
     ctx->timings[0] = 0;
-    for (int i = 1; i <= 2; i++) {
-        ZK_HIP(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
-        ctx->timings[i] = ms;
-    }
+    ZK_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+    ctx->timings[1] = ms;
+    ZK_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    ctx->timings[2] = ms;
+    ZK_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
+    ctx->timings[2] += ms;
     ctx->timings[9] = (float)(now_ms() - t0);
     for (auto &e : ev) (void)hipEventDestroy(e);
 }
@@ -342,8 +350,13 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
         hipDeviceProp_t prop;
         ZK_HIP(hipGetDeviceProperties(&prop, dev));
         ctx->num_cus = prop.multiProcessorCount;
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        // priorities: the short, latency-bound chains (witness map / sorts, fix-ups / reductions) go ahead of the long
+        // throughput-bound accumulations whenever both have work queued
+        int prio_lo = 0, prio_hi = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // lo = least priority (numerically largest)
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo));
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_hi));
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->wm_stream, hipStreamNonBlocking, prio_hi));
     } catch (const HipError &e) {
         int rc = fail(ctx, e);
         delete ctx;
@@ -358,12 +371,17 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
     for (auto &sl : ctx->slots) {
         if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
         if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
         if (sl.red_done) (void)hipEventDestroy(sl.red_done);
         sl.buckets.release();
         sl.wsums_dev.release();
+        sl.seg_head.release();
+        sl.seg_tail.release();
+        sl.seg_meta.release();
+        sl.long_list.release();
     }
     ctx->red_a.release(); ctx->red_b.release(); ctx->red_c.release();
     ctx->pks.clear();
@@ -371,6 +389,7 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     ctx->wits.clear();
     ctx->ntt_tables.clear();
     (void)hipStreamDestroy(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->wm_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -383,8 +402,8 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_window_bits = (int)value;
         return ZKG16_OK;
     }
-    if (!strcmp(name, "g2_last")) {
-        ctx->opt_g2_last = value != 0;
+    if (!strcmp(name, "wm_concurrent")) {      // -1 auto (default), 0 in-order, 1 third stream
+        ctx->opt_wm_concurrent = (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "reduce_chunk")) {

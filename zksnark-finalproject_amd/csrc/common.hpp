@@ -90,7 +90,7 @@ struct R1csDev {
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
-    DevBuf buckets, wsums_dev;
+    DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list;
     void *wsums_host = nullptr;   // pinned
     size_t host_bytes = 0;
     hipEvent_t acc_done = nullptr, red_done = nullptr;
@@ -99,7 +99,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, offsets, seg_meta, seg_head, seg_tail, scalars, long_list, sort_temp;
+    DevBuf keys, entries, offsets, scalars, stage, sort_temp;
 };
 
 }  // namespace zk
@@ -115,8 +115,10 @@ struct zkg16_ctx {
     std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
     uint64_t next_handle = 1;
     zk::MsmWorkspace ws_z, ws_h;                      // one workspace per scalar vector (z-side, h-side)
-    hipStream_t aux_stream = nullptr;                 // bucket reductions run here, overlapping the next accumulation
+    hipStream_t aux_stream = nullptr;                 // fix-ups + bucket reductions run here, overlapping the next accumulation
+    hipStream_t wm_stream = nullptr;                  // witness map + h-side sort of a proof, concurrent with the z-side MSMs
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
+    void *extra_host = nullptr;                       // pinned staging for the r, s, -rs scalars
     zk::DevBuf red_a, red_b, red_c;                   // reduction scratch (aux stream is in-order, so shared)
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
     float timings[16] = {0};
@@ -125,7 +127,7 @@ struct zkg16_ctx {
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
     int opt_reduce_chunk = 0;
-    bool opt_g2_last = false;
+    int opt_wm_concurrent = -1;
     int num_cus = 256;
 };
 
