@@ -403,9 +403,14 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     ZK_HIP(hipGetLastError());
     // the exact entry count stays on the device (offsets[tb]); launches are sized by the bound n * windows
     plan.total_entries = n * (size_t)plan.nwin;
-    // segment length: 64 entries until that would exceed ~2^18 segments (more than enough lanes to fill 256 CUs), then
-    // longer segments — keeps the average bucket inside one segment at large n and the fix-up lists short
-    while (plan.seg_len < 2048 && plan.total_entries / plan.seg_len > ((size_t)1 << 18)) plan.seg_len <<= 1;
+    // segment length: aim at ~2^17 lanes (2048 waves = every SIMD of the chip twice): the smallest power of two >= 3/4 of
+    // entries / 2^17, clamped to [8, 2048].  Small (or sharded) MSMs get short segments so the chip still fills; large ones
+    // get long segments so the average bucket stays inside one segment and the fix-up lists stay short.
+    {
+        const size_t want = plan.total_entries * 3 / 4 / ((size_t)1 << 17);
+        plan.seg_len = 8;
+        while (plan.seg_len < 2048 && (size_t)plan.seg_len < want) plan.seg_len <<= 1;
+    }
     plan.nseg = (plan.total_entries + plan.seg_len - 1) / plan.seg_len;
 }
 
