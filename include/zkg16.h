@@ -125,6 +125,13 @@ ZKG16_API int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t t
                 uint64_t alpha_g1[12], uint64_t beta_g1[12], uint64_t beta_g2[24], uint64_t delta_g1[12], uint64_t delta_g2[24],
                 uint64_t gamma_g2[24], uint64_t *gamma_abc_g1 /* num_instance x 12 */);
 
+/* ---- Groth16 verification on the host (scope row f-3; no ctx, no GPU): `verify_with_processed_vk` of the handlers
+ * (matrix_proof.rs:200-205).  gamma_abc_g1: num_instance points; public_inputs: num_instance - 1 Montgomery Fr; *ok = 1 iff
+ * e(A,B) = e(alpha,beta) e(sum z_i gamma_abc_i, gamma) e(C,delta). */
+ZKG16_API int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t gamma_g2[24], const uint64_t delta_g2[24],
+                 const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs,
+                 const uint64_t proof[48], const uint8_t inf[3], int *ok);
+
 /* ---- host-side circuit synthesis (row a2: stays on the host; no ctx, no GPU).  C++ mirrors of the reference's circuits with
  * the same allocation order (variable k here = variable k in arkworks):
  *   MatrixCircuit     src/arkworks/matrix_proof_of_work/constraints.rs:78-128 (+ Poseidon hasher.rs:17-40, hashing_utils.rs:15-877)

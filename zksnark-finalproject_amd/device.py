@@ -235,3 +235,17 @@ def _setup(self, r1cs_h, num_instance, num_vars, domain, trapdoor_mont, g1_gen, 
 
 
 Device.setup = _setup
+
+
+def verify(vk, public_inputs_mont, proof48, inf3):
+    """Host-only Groth16 verification (zkg16_verify).  vk: dict alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (n x 12)."""
+    lib = _lib.load()
+    gabc = _u64(vk["gamma_abc_g1"]).reshape(-1, 12)
+    pub = _u64(public_inputs_mont).reshape(-1, 4)
+    assert pub.shape[0] == gabc.shape[0] - 1
+    ok = C.c_int(0)
+    rc = lib.zkg16_verify(_u64(vk["alpha_g1"]), _u64(vk["beta_g2"]), _u64(vk["gamma_g2"]), _u64(vk["delta_g2"]), gabc, gabc.shape[0],
+                          _ptr(pub) if pub.size else None, _u64(proof48), np.ascontiguousarray(inf3, dtype=np.uint8), C.byref(ok))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return bool(ok.value)

@@ -62,3 +62,13 @@ def prove_fibonacci(dev, a, b, num_of_rounds, seed=42):
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
                 fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], _detail=out, _circuit=circ)
+
+
+def verify_proof(vk, public_inputs_mont, proof_b64):
+    """Mirror of the verify handlers (matrix_proof.rs:183-205, fibbonaci_handler.rs:118-145): decode the base64 compressed
+    proof, check the Groth16 equation with the host verifier (zkg16_verify) -> {valid, verifying_time}."""
+    from .device import verify
+    t0 = time.perf_counter()
+    proof, inf = wire.decode_proof(proof_b64)
+    ok = verify(vk, public_inputs_mont, proof, inf)
+    return dict(valid=bool(ok), verifying_time=time.perf_counter() - t0)
