@@ -26,8 +26,9 @@ ScopedKernelTimer::~ScopedKernelTimer() {
 void kernel_timer_resolve(zkg16_ctx *ctx) {
     if (ctx->pending_events.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->wm_stream);
+    for (auto &sl : ctx->slots)
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     for (auto &p : ctx->pending_events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -355,7 +356,6 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
         int prio_lo = 0, prio_hi = 0;
         ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // lo = least priority (numerically largest)
         ZK_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo));
-        ZK_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_hi));
         ZK_HIP(hipStreamCreateWithPriority(&ctx->wm_stream, hipStreamNonBlocking, prio_hi));
     } catch (const HipError &e) {
         int rc = fail(ctx, e);
@@ -370,7 +370,7 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamSynchronize(ctx->wm_stream);
     if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
     for (auto &sl : ctx->slots) {
         if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
@@ -382,13 +382,13 @@ void zkg16_destroy(zkg16_ctx *ctx) {
         sl.seg_tail.release();
         sl.seg_meta.release();
         sl.long_list.release();
+        sl.red_a.release(); sl.red_b.release(); sl.red_c.release();
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
     }
-    ctx->red_a.release(); ctx->red_b.release(); ctx->red_c.release();
     ctx->pks.clear();
     ctx->r1cs.clear();
     ctx->wits.clear();
     ctx->ntt_tables.clear();
-    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->wm_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

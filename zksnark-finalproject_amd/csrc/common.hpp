@@ -90,7 +90,8 @@ struct R1csDev {
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
-    DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list;
+    DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list, red_a, red_b, red_c;
+    hipStream_t stream = nullptr;   // this MSM's reduction runs here
     void *wsums_host = nullptr;   // pinned
     size_t host_bytes = 0;
     hipEvent_t acc_done = nullptr, red_done = nullptr;
@@ -115,11 +116,9 @@ struct zkg16_ctx {
     std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
     uint64_t next_handle = 1;
     zk::MsmWorkspace ws_z, ws_h;                      // one workspace per scalar vector (z-side, h-side)
-    hipStream_t aux_stream = nullptr;                 // fix-ups + bucket reductions run here, overlapping the next accumulation
     hipStream_t wm_stream = nullptr;                  // witness map + h-side sort of a proof, concurrent with the z-side MSMs
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
     void *extra_host = nullptr;                       // pinned staging for the r, s, -rs scalars
-    zk::DevBuf red_a, red_b, red_c;                   // reduction scratch (aux stream is in-order, so shared)
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
     float timings[16] = {0};
     bool kernel_timing = false;

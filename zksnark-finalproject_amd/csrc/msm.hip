@@ -431,6 +431,7 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     if (!slot.acc_done) {
         ZK_HIP(hipEventCreateWithFlags(&slot.acc_done, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&slot.red_done, hipEventDisableTiming));
+        ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     }
     slot.buckets.ensure(tb * psz);
     slot.seg_head.ensure(plan.nseg * psz);
@@ -476,18 +477,20 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(slot.acc_done, ctx->stream));
 
-    // ---- aux stream: the weighted bucket reduction, while the main stream already runs the next MSM's accumulation
-    hipStream_t aux = ctx->aux_stream;
+    // ---- this slot's own stream: the weighted bucket reduction, while the main stream already runs the next MSM's
+    // accumulation; the five reductions of a proof are latency-bound chains on a few hundred waves each, so they also run
+    // concurrently with each other
+    hipStream_t aux = slot.stream;
     ZK_HIP(hipStreamWaitEvent(aux, slot.acc_done, 0));
     const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
     int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : 8;
     while ((size_t)kk > plan.nb) kk >>= 1;
     const size_t nchunks = plan.nb / kk;
     const size_t tot = nchunks * plan.nwin;
-    ctx->red_a.ensure(tot * psz);
-    ctx->red_b.ensure(tot * psz);
-    ctx->red_c.ensure(tot * psz);
-    XYZZ<F> *pa = ctx->red_a.as<XYZZ<F>>(), *pb = ctx->red_b.as<XYZZ<F>>(), *pc = ctx->red_c.as<XYZZ<F>>();
+    slot.red_a.ensure(tot * psz);
+    slot.red_b.ensure(tot * psz);
+    slot.red_c.ensure(tot * psz);
+    XYZZ<F> *pa = slot.red_a.as<XYZZ<F>>(), *pb = slot.red_b.as<XYZZ<F>>(), *pc = slot.red_c.as<XYZZ<F>>();
     const unsigned rgrid = (unsigned)((tot + 63) / 64);
     {
         ScopedKernelTimer kt(ctx, rname, (double)tb, aux);
