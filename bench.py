@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--matrix-n", type=int, default=32, help="n of the n x n matrix-mul circuit (32 = configs[1], 46 = 2^20 domain)")
+    ap.add_argument("--workload", default="matrix", choices=["matrix", "prime_like"],
+                    help="matrix = the reference's MatrixCircuit (metric workload); prime_like = bit-heavy circuit of configs[4]'s shape")
     ap.add_argument("--synthetic-rows", action="store_true", help="shape-exact synthetic rows instead of the synthesized MatrixCircuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: several ranks on one GPU)")
@@ -130,7 +132,10 @@ def main():
     from zksnark_finalproject_amd.workloads import matmul_like_r1cs
 
     dev = Device(dev_index)
-    if args.synthetic_rows:
+    if args.workload == "prime_like":
+        from zksnark_finalproject_amd.workloads import prime_like_r1cs
+        r1cs, z, shp = prime_like_r1cs()
+    elif args.synthetic_rows:
         r1cs, z, shp = matmul_like_r1cs(args.matrix_n)      # same seed on every rank
     else:
         # the reference's MatrixCircuit itself (C++ mirror, csrc/circuits.hip) on bench/matrix.py:11's all-ones inputs
@@ -200,13 +205,16 @@ def main():
         # HBM traffic of one msm_accumulate_g1 launch from rocprofv3 PMC passes of this same command (profiles/
         # rocprofv3_pmc_r1_fetch_write.txt: FETCH_SIZE + WRITE_SIZE, calibrated on ntt_pass_cols: no 2x for 112-B gathers);
         # only known for the default workload on one GPU
-        traffic = 1.05e9 if (world == 1 and args.matrix_n == 32) else None
+        traffic = 1.05e9 if (world == 1 and args.matrix_n == 32 and args.workload == "matrix") else None
         out = {
             "metric": "groth16_proofs_per_sec", "value": args.steps / dt, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "matrix-mul %dx%d + Poseidon circuit (BASELINE configs[1] when n=32): %d constraints, %d witness vars, domain 2^%d; "
+            "config": {"workload": ("Fermat-prime-shaped boolean circuit (BASELINE configs[4] shape, synthetic rows): %d constraints, %d witness vars, domain 2^%d; "
+                                    "pk/R1CS/assignment resident in HBM" % (shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1))
+                       if args.workload == "prime_like" else
+                                   "matrix-mul %dx%d + Poseidon circuit (BASELINE configs[1] when n=32): %d constraints, %d witness vars, domain 2^%d; "
                                    "pk/R1CS/assignment resident in HBM; %s; structurally faithful random-point key"
                                    % (args.matrix_n, args.matrix_n, shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1,
                                       "synthetic shape-exact rows" if args.synthetic_rows else "R1CS + witness synthesized by the C++ mirror of the reference's MatrixCircuit on all-ones inputs"),

@@ -414,3 +414,17 @@ def test_concurrent_callers_on_one_ctx(dev, oracle):
         assert np.array_equal(out[i][0], eproof) and np.array_equal(out[i][1], einf)
     for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
         f(hnd)
+
+
+def test_prove_prime_like_bits_workload(dev, oracle):
+    """configs[4] shape: every z-side scalar is 0 or 1 (one giant bucket per MSM): GPU proof == oracle proof."""
+    from zksnark_finalproject_amd.workloads import prime_like_r1cs
+    r1cs, zm, shp = prime_like_r1cs(4000)
+    rng = random.Random(12)
+    pk, _ = synth.make_pk(oracle, r1cs, shp["num_vars"], rng, point_gen=dev.fixed_base)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    ph = dev.pk_load(pk, shp["num_instance"])
+    proof, inf = dev.prove(ph, r, s, r1cs, zm)
+    dev.pk_free(ph)
+    eproof, einf = oracle.prove(pk, r, s, r1cs, zm)
+    assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)

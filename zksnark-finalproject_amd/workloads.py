@@ -106,3 +106,69 @@ def matmul_like_r1cs(n, seed=0x5EED0001):
         c=(np.arange(nc + 1, dtype=np.uint64), np.array(c_cols, dtype=np.uint32), from_canon(to_limbs([1] * nc))),
         num_inputs=4, num_constraints=nc)
     return r1cs, from_canon(to_limbs(z_int)), shp
+
+
+def prime_like_r1cs(nc=230000, seed=0x5EED0004):
+    """Shape of the reference's Fermat-prime circuit (BASELINE configs[4]; SURVEY.md 8d row 4: ~1.3-2.6e5 constraints, domain
+    2^18, 7 SHA-256 compressions + comparisons => nearly every witness is a bit): a satisfiable boolean circuit of AND / XOR /
+    booleanity rows over bit-valued witnesses plus a sprinkling of 20-bit recomposition rows with field-sized quotients.
+    This is a workload generator for the hot path (pathological bucket skew: every z-side scalar is 0 or 1), not a mirror of
+    prime_snark/prime_circut.rs — its SHA-256 gadget constraint layout cannot be checked without ark-crypto-primitives.
+    Returns (r1cs arrays, z Montgomery, shape dict)."""
+    rng = np.random.default_rng(seed)
+    ni = 1 + 1 + 256                                    # one, x, and the 256 digest bits as instance (prime_circut.rs:98-105)
+    z = [1, int(rng.integers(1, 1 << 62))] + [int(b) for b in rng.integers(0, 2, size=256)]
+    rows_a, rows_b, rows_c = [], [], []
+
+    def new_var(v):
+        z.append(v % R_MOD)
+        return len(z) - 1
+
+    bits = list(range(2, 258))                          # pool of bit-valued variables
+    R1 = R_MOD - 1
+    while len(rows_a) < nc:
+        kind = len(rows_a) % 16
+        a, b = bits[int(rng.integers(len(bits)))], bits[int(rng.integers(len(bits)))]
+        if kind < 7:                                    # c = a AND b            : a * b = c
+            c = new_var(z[a] * z[b])
+            rows_a.append([(1, a)]); rows_b.append([(1, b)]); rows_c.append([(1, c)])
+            bits.append(c)
+        elif kind < 13:                                 # c = a XOR b            : (2a) * b = a + b - c
+            c = new_var(z[a] ^ z[b])
+            rows_a.append([(2, a)]); rows_b.append([(1, b)]); rows_c.append([(1, a), (1, b), (R1, c)])
+            bits.append(c)
+        elif kind < 15:                                 # booleanity of a fresh bit: b * (1 - b) = 0
+            c = new_var(int(rng.integers(0, 2)))
+            rows_a.append([(1, c)]); rows_b.append([(1, 0), (R1, c)]); rows_c.append([])
+            bits.append(c)
+        else:                                           # 20-bit recomposition times a random field element = witnessed product
+            sel = [bits[int(rng.integers(len(bits)))] for _ in range(20)]
+            val = sum(z[v] << k for k, v in enumerate(sel))
+            q = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % R_MOD
+            qv = new_var(q)
+            pv = new_var(val * q)
+            rows_a.append([(1 << k, v) for k, v in enumerate(sel)]); rows_b.append([(1, qv)]); rows_c.append([(1, pv)])
+        if len(bits) > 4096:
+            bits = bits[-4096:]
+
+    def to_limbs(vals):
+        out = np.zeros((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            out[i, 0] = v & MASK64; out[i, 1] = (v >> 64) & MASK64; out[i, 2] = (v >> 128) & MASK64; out[i, 3] = v >> 192
+        return out
+
+    def mont(vals):
+        return to_limbs([(v << 256) % R_MOD for v in vals])
+
+    def csr(rows):
+        rp, col, cf = [0], [], []
+        for row in rows:
+            for c, j in row:
+                col.append(j); cf.append(c % R_MOD)
+            rp.append(len(col))
+        return np.array(rp, dtype=np.uint64), np.array(col, dtype=np.uint32), mont(cf) if cf else np.zeros((0, 4), dtype=np.uint64)
+
+    nv = len(z)
+    r1cs = dict(a=csr(rows_a), b=csr(rows_b), c=csr(rows_c), num_inputs=ni, num_constraints=nc)
+    shp = dict(nc=nc, num_instance=ni, num_witness=nv - ni, num_vars=nv, domain=1 << (nc + ni - 1).bit_length())
+    return r1cs, mont(z), shp
