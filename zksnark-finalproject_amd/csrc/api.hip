@@ -164,7 +164,8 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     for (int i = 0; i < 4; i++) ctx->poly[i].ensure(N * sizeof(Fr));
     Fr *zs = ctx->ws_z.scalars.as<Fr>();
     Fr *hs = ctx->ws_h.scalars.as<Fr>();
-    MsmPlan plan_z, plan_h;
+    MsmPlan plan_z, plan_h, plan_zb;
+    const bool b_sparse = pk.b_skipped * 20 > nzs;             // > 5 % of the terms: worth a second (0.3 ms) sort
     ZK_HIP(hipEventRecord(ev[0], ctx->stream));
     {
         if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
@@ -178,6 +179,11 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         ZK_HIP(hipMemcpyAsync(stage + nz, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));   // pinned; reused only after this proof
         fr_from_mont_run(ctx, stage, zs, nzs);
         msm_plan_build(ctx, ctx->ws_z, zs, nzs, plan_z);
+        if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
+            ctx->ws_zb.scalars.ensure(nzs * sizeof(Fr));
+            mask_scalars_run(ctx, zs, pk.b_mask.as<uint8_t>(), ctx->ws_zb.scalars.as<Fr>(), nzs);
+            msm_plan_build(ctx, ctx->ws_zb, ctx->ws_zb.scalars.as<Fr>(), nzs, plan_zb);
+        }
     }
     ZK_HIP(hipEventRecord(ev[1], ctx->stream));
 
@@ -202,10 +208,12 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // ---- queue the five MSMs: accumulations on the main stream (G2 first: its long reduction then hides behind the G1
     // accumulations; H last: it is the only one that waits for the witness map), reductions on the aux stream; then collect —
     // each MSM's host Horner overlaps the device work still queued behind it
-    msm_g2_enqueue(ctx, ctx->ws_z, plan_z, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+    MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
+    const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
+    msm_g2_enqueue(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
     msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
-    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    msm_g1_enqueue(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
     msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
     double tprev = now_ms();
@@ -470,6 +478,8 @@ int zkg16_pk_load(zkg16_ctx *ctx,
     upload_one<G1Affine>(ctx, pk->b1.as<G1AffineU>() + nz + 1, pk->delta_g1);
     upload_one<G2Affine>(ctx, pk->b2.as<G2AffineU>() + nz + 1, pk->delta_g2);
     upload_one<G1Affine>(ctx, pk->l.as<G1AffineU>() + nz + 2, pk->delta_g1);
+    pk->b_mask.alloc(nz + 3);
+    pk->b_skipped = b_density_mask_run(ctx, pk->b1.as<G1AffineU>(), pk->b2.as<G2AffineU>(), nz + 3, pk->b_mask.as<uint8_t>());
     *pk_handle = ctx->next_handle++;
     ctx->pks[*pk_handle] = std::move(pk);
     ZK_API_END(ctx)

@@ -75,6 +75,8 @@ struct PkDev {              // proving key shard resident in HBM (affine AoS; (0
     DevBuf a, b1, l;                                 // G1AffineU[z_hi - z_lo + 3]  (three trailing slots: r, s, -rs terms)
     DevBuf b2;                                       // G2AffineU[z_hi - z_lo + 3]
     DevBuf h;                                        // G1AffineU[h_hi - h_lo]
+    DevBuf b_mask;                                   // u8[z_hi - z_lo + 3]: 1 where the term's base is infinity in both B queries
+    size_t b_skipped = 0;                            // number of such terms (B-side plan is separate when this is worth a sort)
     G1Affine alpha_g1, beta_g1, delta_g1;            // host copies for the tail
     G2Affine beta_g2, delta_g2;
     int shard_index = 0, shard_count = 1;
@@ -100,7 +102,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, offsets, scalars, stage, sort_temp;
+    DevBuf keys, entries, offsets, seg_params, scalars, stage, sort_temp;
 };
 
 }  // namespace zk
@@ -115,7 +117,7 @@ struct zkg16_ctx {
     std::map<uint64_t, std::unique_ptr<zk::R1csDev>> r1cs;
     std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
     uint64_t next_handle = 1;
-    zk::MsmWorkspace ws_z, ws_h;                      // one workspace per scalar vector (z-side, h-side)
+    zk::MsmWorkspace ws_z, ws_h, ws_zb;               // one workspace per scalar vector (z, h, and z masked by the B-query density)
     hipStream_t wm_stream = nullptr;                  // witness map + h-side sort of a proof, concurrent with the z-side MSMs
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
     void *extra_host = nullptr;                       // pinned staging for the r, s, -rs scalars
@@ -161,8 +163,8 @@ struct MsmPlan {
     size_t n = 0;            // scalars
     int c = 0, nwin = 0;     // window bits, window count
     size_t nb = 0;           // buckets per window = 2^(c-1)
-    size_t total_entries = 0, nseg = 0;
-    int seg_len = 0;
+    size_t total_entries = 0;            // upper bound n * windows (the exact count lives on the device)
+    uint32_t lanes_g1 = 0, lanes_g2 = 0; // lanes of one resident round of accumulation waves (2 / 1 waves per SIMD)
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
@@ -186,6 +188,8 @@ G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const 
 void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n);
 void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n);
 
+size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask);
+void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out, size_t n);
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out);
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out);
 

@@ -115,6 +115,18 @@ __global__ void __launch_bounds__(256) msm_offsets_kernel(const uint2 *sorted, s
     offsets[g] = (uint32_t)lo;
 }
 
+// Entries per lane so that ONE full round of resident waves covers the whole list with equal work per lane (no tail, no
+// partially filled second round): seg_len = ceil(entries / lanes), one value per occupancy class
+// (params[0]: G1 kernels, 2 waves/SIMD; params[1]: G2 kernels, 1 wave/SIMD).
+__global__ void msm_seg_params_kernel(const uint32_t *total_ptr, uint32_t lanes_g1, uint32_t lanes_g2, uint32_t *params) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t total = *total_ptr;
+        uint32_t s1 = (total + lanes_g1 - 1) / lanes_g1, s2 = (total + lanes_g2 - 1) / lanes_g2;
+        params[0] = s1 < 4 ? 4 : s1;
+        params[1] = s2 < 4 ? 4 : s2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ base side
 template <class F>
 struct AccArgs {
@@ -125,7 +137,7 @@ struct AccArgs {
     int32_t *seg_meta;          // [2*t] = bucket of head partial or -1, [2*t+1] = bucket of tail partial or -1
     const uint32_t *total_ptr;  // number of sorted entries (= offsets[total_buckets]); read on the device, no host sync
     size_t total_buckets;
-    int seg_len;
+    const uint32_t *seg_len_ptr; // entries per lane, computed on the device from the exact entry count (msm_seg_params_kernel)
 };
 
 // G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
@@ -133,9 +145,10 @@ template <class F>
 __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate_kernel(AccArgs<F> a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *a.total_ptr;
-    const uint32_t start = t * (uint32_t)a.seg_len;
+    const uint32_t seg_len = *a.seg_len_ptr;
+    const uint32_t start = t * seg_len;
     if (start >= total) return;
-    const uint32_t end = start + a.seg_len < total ? start + a.seg_len : total;
+    const uint32_t end = start + seg_len < total ? start + seg_len : total;
     uint2 en = a.entries[start];
     const uint32_t g_first = en.y;
     const bool head_open = start > 0 && a.entries[start - 1].y == g_first;   // first bucket began in an earlier segment
@@ -186,10 +199,11 @@ static constexpr int FIXUP_SHORT = 4;
 template <class F>
 __global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *long_list, uint32_t *long_count) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t * (size_t)a.seg_len >= (size_t)*a.total_ptr) return;
+    const size_t seg_len = *a.seg_len_ptr;
+    if (t * seg_len >= (size_t)*a.total_ptr) return;
     const int32_t g = a.seg_meta[2 * t + 1];
     if (g < 0) return;
-    const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)a.seg_len;   // segment holding the bucket's last term
+    const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / seg_len;   // segment holding the bucket's last term
     if (last_seg - t > FIXUP_SHORT) {
         long_list[atomicAdd(long_count, 1u)] = (uint32_t)t;
         return;
@@ -212,7 +226,7 @@ __global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, const
     for (uint32_t item = blockIdx.x; item < n_long; item += gridDim.x) {
         const size_t t = long_list[item];
         const int32_t g = a.seg_meta[2 * t + 1];
-        const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)a.seg_len;
+        const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)*a.seg_len_ptr;
         XYZZ<F> sum = XYZZ<F>::inf();
         if (threadIdx.x == 0) sum = ldv(a.seg_tail + t);
         for (size_t u = t + 1 + threadIdx.x; u <= last_seg; u += blockDim.x) {
@@ -328,6 +342,45 @@ __global__ void __launch_bounds__(64) convert_wsums_kernel(const XYZZ<FU> *in, s
     stv(out + w, o);
 }
 
+// ------------------------------------------------------------------------------------------------ density of the B queries
+// ark-groth16 keeps one b_query entry per variable even when the variable never occurs on the B side of the R1CS (its
+// v_k(tau) is 0 and the entry is the point at infinity): ~19 % of the MatrixCircuit's variables.  A term whose base is
+// infinity in BOTH b_g1_query and b_g2_query gets scalar 0 in the B-side plan, so it never becomes a bucket entry.
+__global__ void __launch_bounds__(256) b_density_mask_kernel(const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask, uint32_t *count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1AffineU p = ldv(b1 + i);
+    const G2AffineU q = ldv(b2 + i);
+    const bool skip = p.is_inf() && q.is_inf();
+    mask[i] = skip ? 1 : 0;
+    if (skip) atomicAdd(count, 1u);
+}
+__global__ void __launch_bounds__(256) mask_scalars_kernel(const Fr *in, const uint8_t *mask, Fr *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *q = reinterpret_cast<const uint4 *>(in + i);
+    uint4 a = q[0], b = q[1];
+    if (mask[i]) a = b = make_uint4(0, 0, 0, 0);
+    uint4 *o = reinterpret_cast<uint4 *>(out + i);
+    o[0] = a;
+    o[1] = b;
+}
+size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask) {
+    DevBuf cnt(sizeof(uint32_t));
+    ZK_HIP(hipMemsetAsync(cnt.p, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(b_density_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b1, b2, n, mask, cnt.as<uint32_t>());
+    ZK_HIP(hipGetLastError());
+    uint32_t h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return h;
+}
+void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(mask_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, mask, out, n);
+    ZK_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------ fixed base
 template <class F>
 __global__ void __launch_bounds__(64) fixed_base_table_kernel(const XYZZ<F> *win_bases /*32*/, Affine<F> *table /*32*255*/) {
@@ -377,9 +430,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     plan.c = pick_window_bits(ctx, n);
     plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
     plan.nb = (size_t)1 << (plan.c - 1);
-    plan.seg_len = 64;
     plan.total_entries = 0;
-    plan.nseg = 0;
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
     const size_t tot = n * (size_t)plan.nwin;
@@ -401,17 +452,15 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
                            ws.entries.as<uint2>(), tot, ws.offsets.as<uint32_t>(), tb);
     }
     ZK_HIP(hipGetLastError());
-    // the exact entry count stays on the device (offsets[tb]); launches are sized by the bound n * windows
-    plan.total_entries = n * (size_t)plan.nwin;
-    // segment length: aim at ~2^17 lanes (2048 waves = every SIMD of the chip twice): the smallest power of two >= 3/4 of
-    // entries / 2^17, clamped to [8, 2048].  Small (or sharded) MSMs get short segments so the chip still fills; large ones
-    // get long segments so the average bucket stays inside one segment and the fix-up lists stay short.
-    {
-        const size_t want = plan.total_entries * 3 / 4 / ((size_t)1 << 17);
-        plan.seg_len = 8;
-        while (plan.seg_len < 2048 && (size_t)plan.seg_len < want) plan.seg_len <<= 1;
-    }
-    plan.nseg = (plan.total_entries + plan.seg_len - 1) / plan.seg_len;
+    // the exact entry count stays on the device (offsets[tb]); the accumulation grids are one resident round of waves and
+    // the per-lane segment length is derived from the count on the device
+    plan.total_entries = tot;
+    plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * 2u * 64u;
+    plan.lanes_g2 = (uint32_t)ctx->num_cus * 4u * 1u * 64u;
+    ws.seg_params.ensure(2 * sizeof(uint32_t));
+    hipLaunchKernelGGL(msm_seg_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ws.offsets.as<uint32_t>() + tb, plan.lanes_g1, plan.lanes_g2,
+                       ws.seg_params.as<uint32_t>());
+    ZK_HIP(hipGetLastError());
 }
 
 // An MSM runs in two halves on two HIP streams so that the latency-bound bucket reduction of one MSM overlaps the
@@ -434,9 +483,10 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
         ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     }
     slot.buckets.ensure(tb * psz);
-    slot.seg_head.ensure(plan.nseg * psz);
-    slot.seg_tail.ensure(plan.nseg * psz);
-    slot.seg_meta.ensure(plan.nseg * 2 * sizeof(int32_t));
+    const size_t nseg = FieldTraits<F>::g2 ? plan.lanes_g2 : plan.lanes_g1;      // lanes of one resident round
+    slot.seg_head.ensure(nseg * psz);
+    slot.seg_tail.ensure(nseg * psz);
+    slot.seg_meta.ensure(nseg * 2 * sizeof(int32_t));
     ZK_HIP(hipMemsetAsync(slot.buckets.p, 0, tb * psz, ctx->stream));
     AccArgs<F> a;
     a.bases = bases;
@@ -448,8 +498,8 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     a.seg_meta = slot.seg_meta.as<int32_t>();
     a.total_ptr = ws.offsets.as<uint32_t>() + tb;
     a.total_buckets = tb;
-    a.seg_len = plan.seg_len;
-    const unsigned grid = (unsigned)((plan.nseg + 63) / 64);
+    a.seg_len_ptr = ws.seg_params.as<uint32_t>() + (FieldTraits<F>::g2 ? 1 : 0);
+    const unsigned grid = (unsigned)((nseg + 63) / 64);
     {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
         hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
@@ -457,11 +507,11 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     {
         // fix-ups stay on the main stream: measured faster than moving them behind the reductions on the aux stream
         hipStream_t fs = ctx->stream;
-        slot.long_list.ensure((plan.nseg + 1) * sizeof(uint32_t));
+        slot.long_list.ensure((nseg + 1) * sizeof(uint32_t));
         uint32_t *long_list = slot.long_list.as<uint32_t>() + 1, *long_count = slot.long_list.as<uint32_t>();
         ZK_HIP(hipMemsetAsync(long_count, 0, sizeof(uint32_t), fs));
         {
-            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)plan.nseg, fs);
+            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)nseg, fs);
             hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, fs, a, long_list, long_count);
         }
         static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
