@@ -125,6 +125,13 @@ ZKG16_API int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t t
                 uint64_t alpha_g1[12], uint64_t beta_g1[12], uint64_t beta_g2[24], uint64_t delta_g1[12], uint64_t delta_g2[24],
                 uint64_t gamma_g2[24], uint64_t *gamma_abc_g1 /* num_instance x 12 */);
 
+/* Same, but the proving key never leaves the device: returns a pk handle (as zkg16_pk_load would) plus the verifying-key
+ * elements.  This is the per-request flow of the reference's handlers (setup then prove) without the host round trip. */
+ZKG16_API int zkg16_setup_resident(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12],
+                         const uint64_t g2_gen[24], uint64_t *pk_handle,
+                         uint64_t alpha_g1[12], uint64_t beta_g2[24], uint64_t gamma_g2[24], uint64_t delta_g2[24],
+                         uint64_t *gamma_abc_g1 /* num_instance x 12 */);
+
 /* ---- Groth16 verification on the host (scope row f-3; no ctx, no GPU): `verify_with_processed_vk` of the handlers
  * (matrix_proof.rs:200-205).  gamma_abc_g1: num_instance points; public_inputs: num_instance - 1 Montgomery Fr; *ok = 1 iff
  * e(A,B) = e(alpha,beta) e(sum z_i gamma_abc_i, gamma) e(C,delta). */

@@ -327,8 +327,8 @@ def test_handler_mirrors_end_to_end(dev, oracle):
     """prove_matrix / prove_fibonacci (handlers.py: synthesize -> device setup -> device prove -> wire encoding): the proof
     the handler returns decodes to exactly the oracle's proof for the same key, r, s."""
     from zksnark_finalproject_amd import handlers, wire
-    for res in (handlers.prove_matrix(dev, 4, np.ones((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64)),
-                handlers.prove_fibonacci(dev, 0, 1, 100)):
+    for res in (handlers.prove_matrix(dev, 4, np.ones((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64), keep_key=True),
+                handlers.prove_fibonacci(dev, 0, 1, 100, keep_key=True)):
         d, circ = res["_detail"], res["_circuit"]
         proof, inf = wire.decode_proof(res["proof"])
         assert len(wire.proof_serialize_compressed(proof, inf)) == 192
@@ -336,6 +336,20 @@ def test_handler_mirrors_end_to_end(dev, oracle):
         assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
         assert res["proving_time"] > 0 and res["setup_time"] > 0
     assert res["num_constraints"] == 101
+
+
+def test_resident_setup_equals_host_round_trip(dev):
+    """zkg16_setup_resident (key built straight into the device layout) gives the same verifying key and the byte-identical
+    proof as zkg16_setup -> host -> zkg16_pk_load, for the same trapdoor, generators, r, s."""
+    from zksnark_finalproject_amd import handlers
+    for n in (3, 6):
+        a = np.arange(n * n, dtype=np.uint64).reshape(n, n) % 7
+        host = handlers.prove_matrix(dev, n, a, a.T.copy(), seed=5, keep_key=True)
+        res = handlers.prove_matrix(dev, n, a, a.T.copy(), seed=5, keep_key=False)
+        assert res["proof"] == host["proof"]
+        for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1"):
+            assert np.array_equal(res["_detail"]["vk"][k], host["_detail"]["vk"][k]), k
+        assert handlers.verify_proof(res["_detail"]["vk"], res["_circuit"].public_inputs, res["proof"])["valid"]
 
 
 def test_setup_prove_verify_with_pairings(dev):

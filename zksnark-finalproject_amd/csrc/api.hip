@@ -638,6 +638,27 @@ int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20
     ZK_API_END(ctx)
 }
 
+int zkg16_setup_resident(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12], const uint64_t g2_gen[24],
+                         uint64_t *pk_handle, uint64_t alpha_g1[12], uint64_t beta_g2[24], uint64_t gamma_g2[24], uint64_t delta_g2[24],
+                         uint64_t *gamma_abc_g1) {
+    if (!trapdoor || !g1_gen || !g2_gen || !pk_handle || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    if (!rc) return ZKG16_ERR_BAD_HANDLE;
+    Fr trap[5];
+    memcpy(trap, trapdoor, sizeof trap);
+    for (int i = 0; i < 5; i++)
+        if (trap[i].is_zero()) return ZKG16_ERR_BAD_ARG;
+    auto pk = std::make_unique<PkDev>();
+    uint64_t beta_g1[12], delta_g1[12];
+    SetupOut o{nullptr, nullptr, nullptr, nullptr, nullptr, gamma_abc_g1, nullptr, nullptr, nullptr, nullptr,
+               alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2};
+    setup_run(ctx, *rc, trap, g1_from_abi(g1_gen, 0), g2_from_abi(g2_gen, 0), o, pk.get());
+    *pk_handle = ctx->next_handle++;
+    ctx->pks[*pk_handle] = std::move(pk);
+    ZK_API_END(ctx)
+}
+
 // ------------------------------------------------------------------------------------------------ stages
 int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int coset) {
     if (!data) return ZKG16_ERR_BAD_ARG;

@@ -175,7 +175,7 @@ struct SetupOut {
     uint8_t *a_inf, *b_g1_inf, *b_g2_inf, *l_inf;
     uint64_t *alpha_g1, *beta_g1, *beta_g2, *delta_g1, *delta_g2, *gamma_g2;
 };
-void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out);
+void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out, PkDev *resident = nullptr);
 void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);

@@ -45,17 +45,62 @@ __global__ void __launch_bounds__(256) setup_col_offsets_kernel(const uint2 *sor
     offsets[k] = (uint32_t)lo;
 }
 // out[k] = sum over the entries of column k of coeff[e] * L[row[e]]   (+ L[nc + k] for k < num_instance when add_inputs)
+// Columns longer than COL_HEAVY entries (the constant-one column of a Poseidon-heavy circuit holds ~10^5) are queued for
+// setup_col_sum_heavy_kernel instead of being walked by one lane.
+constexpr uint32_t COL_HEAVY = 128;
+constexpr uint32_t COL_HEAVY_MAX = 4096;      // queue capacity; overflow falls back to the serial walk
 __global__ void __launch_bounds__(256) setup_col_sum_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
-                                                            const Fr *L, size_t ncols, size_t nc, size_t num_instance, int add_inputs, Fr *out) {
+                                                            const Fr *L, size_t ncols, size_t nc, size_t num_instance, int add_inputs, Fr *out,
+                                                            uint32_t *heavy /* [0] = count, then column ids */) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncols) return;
+    const uint32_t lo = offsets[k], hi = offsets[k + 1];
+    if (hi - lo > COL_HEAVY) {
+        const uint32_t slot = atomicAdd(heavy, 1u);
+        if (slot < COL_HEAVY_MAX) {
+            heavy[1 + slot] = (uint32_t)k;
+            return;
+        }
+    }
     Fr acc = Fr::zero();
-    for (uint32_t p = offsets[k]; p < offsets[k + 1]; p++) {
+    for (uint32_t p = lo; p < hi; p++) {
         const uint32_t e = sorted[p].x;
         acc = fp_add(acc, fp_mul(ld_fr(coeff + e), ld_fr(L + rowid[e])));
     }
     if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
     st_fr(out + k, acc);
+}
+// one 256-lane block per queued column: strided partial sums, then an LDS tree
+__global__ void __launch_bounds__(256) setup_col_sum_heavy_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
+                                                                  const Fr *L, size_t nc, size_t num_instance, int add_inputs, Fr *out,
+                                                                  const uint32_t *heavy) {
+    __shared__ uint32_t part[8][256];
+    const uint32_t cnt = heavy[0] < COL_HEAVY_MAX ? heavy[0] : COL_HEAVY_MAX;
+    for (uint32_t q = blockIdx.x; q < cnt; q += gridDim.x) {
+        const uint32_t k = heavy[1 + q];
+        const uint32_t lo = offsets[k], hi = offsets[k + 1];
+        Fr acc = Fr::zero();
+        for (uint32_t p = lo + threadIdx.x; p < hi; p += 256) {
+            const uint32_t e = sorted[p].x;
+            acc = fp_add(acc, fp_mul(ld_fr(coeff + e), ld_fr(L + rowid[e])));
+        }
+        for (int i = 0; i < 8; i++) part[i][threadIdx.x] = acc.l[i];
+        __syncthreads();
+        for (int step = 128; step >= 1; step >>= 1) {
+            if ((int)threadIdx.x < step) {
+                Fr o;
+                for (int i = 0; i < 8; i++) o.l[i] = part[i][threadIdx.x + step];
+                acc = fp_add(acc, o);
+                for (int i = 0; i < 8; i++) part[i][threadIdx.x] = acc.l[i];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
+            st_fr(out + k, acc);
+        }
+        __syncthreads();
+    }
 }
 // lg[k] = (beta u_k + alpha v_k + w_k) * (k < num_instance ? gamma^-1 : delta^-1)
 __global__ void __launch_bounds__(256) setup_lg_kernel(const Fr *u, const Fr *v, const Fr *w, Fr alpha, Fr beta, Fr ginv, Fr dinv, size_t ncols,
@@ -66,12 +111,18 @@ __global__ void __launch_bounds__(256) setup_lg_kernel(const Fr *u, const Fr *v,
     st_fr(lg + k, fp_mul(x, k < num_instance ? ginv : dinv));
 }
 
-static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf) {
+static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf,
+                      G1AffineU *resident = nullptr) {
     if (!n) return;
     canon.ensure(n * sizeof(Fr));
     pts.ensure(n * sizeof(G1Affine));
     fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
     fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, pts.as<G1Affine>());
+    if (resident) {                                   // key stays on the device: straight into the unsaturated pk layout
+        convert_g1_bases(ctx, pts.as<G1Affine>(), resident, n);
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
     ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (inf) {
@@ -79,12 +130,18 @@ static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont,
         for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
     }
 }
-static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf) {
+static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf,
+                      G2AffineU *resident = nullptr) {
     if (!n) return;
     canon.ensure(n * sizeof(Fr));
     pts.ensure(n * sizeof(G2Affine));
     fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
     fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, pts.as<G2Affine>());
+    if (resident) {
+        convert_g2_bases(ctx, pts.as<G2Affine>(), resident, n);
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
     ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (inf) {
@@ -93,7 +150,7 @@ static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont,
     }
 }
 
-void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out) {
+void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out, PkDev *res) {
     const Fr &tau = trap[0], &alpha = trap[1], &beta = trap[2], &gamma = trap[3], &delta = trap[4];
     const size_t N = (size_t)1 << m.log_n, nc = m.num_constraints, ni = m.num_instance, nv = m.num_variables;
     Fr zt = tau;
@@ -109,7 +166,7 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
 
     // u, v, w: per-matrix column sums
     DevBuf uvw[3];
-    DevBuf keys, sorted, rowid, coloff, sort_temp;
+    DevBuf keys, sorted, rowid, coloff, sort_temp, heavy((1 + COL_HEAVY_MAX) * sizeof(uint32_t));
     unsigned key_bits = 1;
     while (((size_t)1 << key_bits) <= nv) key_bits++;
     for (int k = 0; k < 3; k++) {
@@ -126,8 +183,12 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
         }
         hipLaunchKernelGGL(setup_col_offsets_kernel, dim3((unsigned)((nv + 1 + 255) / 256)), dim3(256), 0, ctx->stream, sorted.as<uint2>(), nnz,
                            coloff.as<uint32_t>(), nv);
+        ZK_HIP(hipMemsetAsync(heavy.p, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(setup_col_sum_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, sorted.as<uint2>(),
-                           coloff.as<uint32_t>(), rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nv, nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>());
+                           coloff.as<uint32_t>(), rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nv, nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>(),
+                           heavy.as<uint32_t>());
+        hipLaunchKernelGGL(setup_col_sum_heavy_kernel, dim3(512), dim3(256), 0, ctx->stream, sorted.as<uint2>(), coloff.as<uint32_t>(),
+                           rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>(), heavy.as<uint32_t>());
         ZK_HIP(hipGetLastError());
     }
     DevBuf lg(nv * sizeof(Fr));
@@ -138,11 +199,22 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
     fr_powers_run(ctx, L.as<Fr>(), tau, fp_mul(zt, dinv), N - 1);
 
     DevBuf canon, pts;
-    points_g1(ctx, g1, uvw[0].as<Fr>(), nv, canon, pts, out.a_query, out.a_inf);
-    points_g1(ctx, g1, uvw[1].as<Fr>(), nv, canon, pts, out.b_g1_query, out.b_g1_inf);
-    points_g2(ctx, g2, uvw[1].as<Fr>(), nv, canon, pts, out.b_g2_query, out.b_g2_inf);
-    points_g1(ctx, g1, L.as<Fr>(), N - 1, canon, pts, out.h_query, nullptr);
-    points_g1(ctx, g1, lg.as<Fr>() + ni, nv - ni, canon, pts, out.l_query, out.l_inf);
+    if (res) {      // resident key (whole key on this device): layouts as in zkg16_pk_load with shard 0 of 1
+        res->num_instance = ni; res->m_total = nv; res->n_h_total = N - 1;
+        res->z_lo = 0; res->z_hi = nv; res->h_lo = 0; res->h_hi = N - 1;
+        res->shard_index = 0; res->shard_count = 1;
+        res->a.alloc((nv + 3) * sizeof(G1AffineU)); res->b1.alloc((nv + 3) * sizeof(G1AffineU)); res->l.alloc((nv + 3) * sizeof(G1AffineU));
+        res->b2.alloc((nv + 3) * sizeof(G2AffineU)); res->h.alloc((N > 1 ? N - 1 : 1) * sizeof(G1AffineU));
+        ZK_HIP(hipMemsetAsync(res->a.p, 0, res->a.bytes, ctx->stream));
+        ZK_HIP(hipMemsetAsync(res->b1.p, 0, res->b1.bytes, ctx->stream));
+        ZK_HIP(hipMemsetAsync(res->l.p, 0, res->l.bytes, ctx->stream));
+        ZK_HIP(hipMemsetAsync(res->b2.p, 0, res->b2.bytes, ctx->stream));
+    }
+    points_g1(ctx, g1, uvw[0].as<Fr>(), nv, canon, pts, out.a_query, out.a_inf, res ? res->a.as<G1AffineU>() : nullptr);
+    points_g1(ctx, g1, uvw[1].as<Fr>(), nv, canon, pts, out.b_g1_query, out.b_g1_inf, res ? res->b1.as<G1AffineU>() : nullptr);
+    points_g2(ctx, g2, uvw[1].as<Fr>(), nv, canon, pts, out.b_g2_query, out.b_g2_inf, res ? res->b2.as<G2AffineU>() : nullptr);
+    points_g1(ctx, g1, L.as<Fr>(), N - 1, canon, pts, out.h_query, nullptr, res ? res->h.as<G1AffineU>() : nullptr);
+    points_g1(ctx, g1, lg.as<Fr>() + ni, nv - ni, canon, pts, out.l_query, out.l_inf, res ? res->l.as<G1AffineU>() + ni : nullptr);
     points_g1(ctx, g1, lg.as<Fr>(), ni, canon, pts, out.gamma_abc_g1, nullptr);
     // alpha, beta, delta (G1) ; beta, delta, gamma (G2)
     Fr singles[4] = {alpha, beta, delta, gamma};
@@ -152,6 +224,20 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
     uint64_t o1[4 * 12], o2[4 * 24];
     points_g1(ctx, g1, d_s.as<Fr>(), 4, canon, pts, o1, nullptr);
     points_g2(ctx, g2, d_s.as<Fr>(), 4, canon, pts, o2, nullptr);
+    if (res) {
+        memcpy(&res->alpha_g1, o1, 96); memcpy(&res->beta_g1, o1 + 12, 96); memcpy(&res->delta_g1, o1 + 24, 96);
+        memcpy(&res->beta_g2, o2 + 24, 192); memcpy(&res->delta_g2, o2 + 48, 192);
+        // extra slots (scalars r, s, -rs): a += r*delta1 ; b1 += s*delta1 ; b2 += s*delta2 ; l += (-rs)*delta1
+        const G1AffineU d1{to_u(res->delta_g1.x), to_u(res->delta_g1.y)};
+        const G2AffineU d2{to_u(res->delta_g2.x), to_u(res->delta_g2.y)};
+        ZK_HIP(hipMemcpyAsync(res->a.as<G1AffineU>() + nv + 0, &d1, sizeof d1, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(res->b1.as<G1AffineU>() + nv + 1, &d1, sizeof d1, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(res->b2.as<G2AffineU>() + nv + 1, &d2, sizeof d2, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(res->l.as<G1AffineU>() + nv + 2, &d1, sizeof d1, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        res->b_mask.alloc(nv + 3);
+        res->b_skipped = b_density_mask_run(ctx, res->b1.as<G1AffineU>(), res->b2.as<G2AffineU>(), nv + 3, res->b_mask.as<uint8_t>());
+    }
     memcpy(out.alpha_g1, o1, 96);
     memcpy(out.beta_g1, o1 + 12, 96);
     memcpy(out.delta_g1, o1 + 24, 96);

@@ -249,3 +249,16 @@ def verify(vk, public_inputs_mont, proof48, inf3):
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     return bool(ok.value)
+
+
+def _setup_resident(self, r1cs_h, num_instance, trapdoor_mont, g1_gen, g2_gen):
+    """Groth16 setup with the key kept on the device (zkg16_setup_resident) -> (pk handle, vk dict)."""
+    vk = dict(alpha_g1=np.zeros(12, np.uint64), beta_g2=np.zeros(24, np.uint64), gamma_g2=np.zeros(24, np.uint64),
+              delta_g2=np.zeros(24, np.uint64), gamma_abc_g1=np.zeros((num_instance, 12), np.uint64))
+    h = C.c_uint64()
+    self._check(self.lib.zkg16_setup_resident(self.ctx, r1cs_h, _u64(trapdoor_mont).reshape(-1), _u64(g1_gen), _u64(g2_gen), C.byref(h),
+                                              vk["alpha_g1"], vk["beta_g2"], vk["gamma_g2"], vk["delta_g2"], vk["gamma_abc_g1"]))
+    return h.value, vk
+
+
+Device.setup_resident = _setup_resident

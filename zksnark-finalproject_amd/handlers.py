@@ -20,7 +20,7 @@ def _fr_mont(x):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
-def _setup_and_prove(dev, circ, rng):
+def _setup_and_prove(dev, circ, rng, keep_key=False):
     trap = np.stack([_fr_mont(rng.randrange(1, R_MOD)) for _ in range(5)])
     # arkworks draws random generators; any subgroup generator gives a valid key: [k]G for random k
     k = np.stack([np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)])
@@ -28,8 +28,12 @@ def _setup_and_prove(dev, circ, rng):
     g2 = dev.fixed_base("g2", g2_generator(), k)[0][0]
     rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
     t0 = time.perf_counter()
-    pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)
-    ph = dev.pk_load(pk, circ.num_instance)
+    if keep_key:        # tests want the key on the host as well
+        pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)
+        ph = dev.pk_load(pk, circ.num_instance)
+    else:               # the request path: the key never leaves the device
+        pk = None
+        ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
     setup_time = time.perf_counter() - t0
     wh = dev.witness_load(circ.z)
     r, s = _fr_mont(rng.randrange(R_MOD)), _fr_mont(rng.randrange(R_MOD))
@@ -41,12 +45,12 @@ def _setup_and_prove(dev, circ, rng):
     return dict(proof=proof, inf=inf, vk=vk, pk=pk, setup_time=setup_time, proving_time=proving_time, r=r, s=s)
 
 
-def prove_matrix(dev, size, matrix_a, matrix_b, seed=0):
+def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
     """-> the reference's ProveOutput fields (matrix_proof.rs:80-91)."""
     a = np.asarray(matrix_a, dtype=np.uint64).reshape(size, size)
     b = np.asarray(matrix_b, dtype=np.uint64).reshape(size, size)
     circ = matrix_circuit(a, b)
-    out = _setup_and_prove(dev, circ, random.Random(seed))
+    out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     ha, hb, hc = circ.public_inputs
     return dict(hash_a=wire.encode_hash(ha), hash_b=wire.encode_hash(hb), hash_c=wire.encode_hash(hc),
                 setup_time=out["setup_time"], proving_time=out["proving_time"],
@@ -55,10 +59,10 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0):
                 num_variables=circ.num_instance, proof=wire.encode_proof(out["proof"], out["inf"]), _detail=out, _circuit=circ)
 
 
-def prove_fibonacci(dev, a, b, num_of_rounds, seed=42):
+def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
     """-> the reference's OutputDataFib-like fields (fibbonaci_handler.rs:84-90)."""
     circ = fibonacci_circuit(a, b, num_of_rounds)
-    out = _setup_and_prove(dev, circ, random.Random(seed))
+    out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
                 fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], _detail=out, _circuit=circ)
