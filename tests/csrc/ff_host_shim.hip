@@ -52,8 +52,10 @@ template <class FS, class FU> static void fieldu_op(int op, const uint32_t *a, c
         case 1: r = f_sub(x, y); break;
         case 2: r = f_mul(x, y); break;
         case 3: r = f_sqr(x); break;
+        case 4: r = f_inv(x); break;
         case 5: r = f_neg(x); break;
         case 6: r = f_sub2(x, y); break;
+        case 8: r = f_tidy(f_mul(f_inv(f_mul(x, y)), y)); break;      // inverse of an un-reduced product, tidied: == 1/x
         case 7: {   // bound stress: a long un-reduced expression inside the documented limits
             FU t = f_sub2(f_mul(x, y), f_sub(f_add(x, y), f_dbl(y)));      // < 2q + 64q
             FU u = f_sub(f_sqr(t), f_add(f_mul(t, x), f_dbl(f_mul(t, y)))); // < 42q

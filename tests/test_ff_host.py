@@ -134,6 +134,23 @@ def test_fqu_field_ops_vs_python(shim):
         assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 7, fq_mont(a), fq_mont(b)))) == exp
 
 
+def test_fqu_inverse_vs_python(shim):
+    """fqu_inv / Fq2U f_inv / f_tidy (the batched to-affine of the setup's fixed-base multiplication)."""
+    rng = random.Random(23)
+    q = P.Q_MOD
+    for a in [1, 2, q - 1] + [rng.randrange(1, q) for _ in range(6)]:
+        b = rng.randrange(1, q)
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 4, fq_mont(a), fq_mont(b)))) == pow(a, q - 2, q)
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 8, fq_mont(a), fq_mont(b)))) == pow(a, q - 2, q)
+    enc = lambda p: np.concatenate([fq_mont(p.c0), fq_mont(p.c1)])
+    dec = lambda a: P.Fq2(P.fq_from_mont(unlimbs(a[:6])), P.fq_from_mont(unlimbs(a[6:])))
+    for _ in range(5):
+        a = P.Fq2(rng.randrange(q), rng.randrange(1, q))
+        b = P.Fq2(rng.randrange(1, q), rng.randrange(q))
+        assert dec(call_field(shim, "ht_fq2u_op", 4, enc(a), enc(b))) == a.inv()
+        assert dec(call_field(shim, "ht_fq2u_op", 8, enc(a), enc(b))) == a.inv()
+
+
 def test_fqu_is_zero_mod(shim):
     for k in (0, 1, 2, 3, 7, 33, 63, 64, 74, 100, 127, 148, 1000, 4000):
         assert shim.ht_fqu_is_zero_mod_k(k, 0) == 1, k

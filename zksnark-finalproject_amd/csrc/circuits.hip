@@ -56,7 +56,13 @@ struct Lc {
 struct Circuit {
     std::vector<Fr> instance;              // instance[0] = 1
     std::vector<Fr> witness;
-    std::vector<std::vector<Term>> rows[3];
+    // constraint rows of A, B, C in flat CSR form (one allocation per matrix, not one per row)
+    struct Rows {
+        std::vector<uint64_t> ptr{0};
+        std::vector<Term> t;
+        size_t size() const { return ptr.size() - 1; }
+        void push(const std::vector<Term> &row) { t.insert(t.end(), row.begin(), row.end()); ptr.push_back(t.size()); }
+    } rows[3];
 
     Circuit() { instance.push_back(Fr::one()); }
 
@@ -111,9 +117,9 @@ struct Circuit {
     }
     static Lc sub(const Lc &a, const Lc &b) { return add(a, scale(b, fp_neg(Fr::one()))); }
     void enforce(const Lc &a, const Lc &b, const Lc &c) {
-        rows[0].push_back(a.t);
-        rows[1].push_back(b.t);
-        rows[2].push_back(c.t);
+        rows[0].push(a.t);
+        rows[1].push(b.t);
+        rows[2].push(c.t);
     }
     // FpVar * FpVar
     Lc mul(const Lc &a, const Lc &b) {
@@ -139,9 +145,10 @@ struct Circuit {
     }
     bool satisfied() const {
         const size_t ni = instance.size();
-        auto eval = [&](const std::vector<Term> &row) {
+        auto eval = [&](const Rows &m, size_t i) {
             Fr acc = Fr::zero();
-            for (const Term &x : row) {
+            for (uint64_t k = m.ptr[i]; k < m.ptr[i + 1]; k++) {
+                const Term &x = m.t[k];
                 const Fr &v = (x.v & WIT) ? witness[x.v & ~WIT] : instance[x.v];
                 acc = fp_add(acc, fp_mul(x.c, v));
             }
@@ -149,7 +156,7 @@ struct Circuit {
         };
         (void)ni;
         for (size_t i = 0; i < rows[0].size(); i++)
-            if (fp_mul(eval(rows[0][i]), eval(rows[1][i])) != eval(rows[2][i])) return false;
+            if (fp_mul(eval(rows[0], i), eval(rows[1], i)) != eval(rows[2], i)) return false;
         return true;
     }
 };
@@ -327,11 +334,7 @@ int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num
     if (num_witness) *num_witness = c->cs.witness.size();
     if (num_constraints) *num_constraints = c->cs.rows[0].size();
     if (nnz)
-        for (int m = 0; m < 3; m++) {
-            size_t k = 0;
-            for (const auto &r : c->cs.rows[m]) k += r.size();
-            nnz[m] = k;
-        }
+        for (int m = 0; m < 3; m++) nnz[m] = c->cs.rows[m].t.size();
     return ZKG16_OK;
 }
 
@@ -343,16 +346,13 @@ int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uin
     if (!c || !row_ptr || !col || !coeff || !z) return ZKG16_ERR_BAD_ARG;
     const size_t ni = c->cs.instance.size();
     for (int m = 0; m < 3; m++) {
-        size_t k = 0;
-        row_ptr[m][0] = 0;
-        for (size_t i = 0; i < c->cs.rows[m].size(); i++) {
-            // instance columns first, then witnesses: sort by final column (ids are already ordered that way)
-            for (const Term &t : c->cs.rows[m][i]) {
-                col[m][k] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
-                memcpy(coeff[m] + 4 * k, t.c.l, 32);
-                k++;
-            }
-            row_ptr[m][i + 1] = k;
+        const Circuit::Rows &r = c->cs.rows[m];
+        memcpy(row_ptr[m], r.ptr.data(), r.ptr.size() * sizeof(uint64_t));
+        // instance columns first, then witnesses (ids are already ordered that way within a row)
+        for (size_t k = 0; k < r.t.size(); k++) {
+            const Term &t = r.t[k];
+            col[m][k] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
+            memcpy(coeff[m] + 4 * k, t.c.l, 32);
         }
     }
     memcpy(z, c->cs.instance.data(), ni * 32);

@@ -55,6 +55,12 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// fixed-base scalar multiplication (setup): window table of the last generator used + scratch, kept across calls
+struct FixedBaseCache {
+    std::vector<uint8_t> key;      // the generator's bytes
+    DevBuf table, sums, pref;
+};
+
 // Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg reads these).
 struct KernelStat { uint64_t launches = 0; double ms = 0, units = 0; };
 struct PendingEvent;
@@ -130,6 +136,7 @@ struct zkg16_ctx {
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
     int num_cus = 256;
+    zk::FixedBaseCache fb_g1, fb_g2;
 };
 
 namespace zk {
@@ -190,7 +197,8 @@ void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t
 
 size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask);
 void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out, size_t n);
-void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out);
-void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out);
+// device outputs; either may be null: saturated (arkworks layout, host-bound) and/or unsaturated (device-resident key)
+void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out_sat, G1AffineU *out_u = nullptr);
+void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out_sat, G2AffineU *out_u = nullptr);
 
 }  // namespace zk

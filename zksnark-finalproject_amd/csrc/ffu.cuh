@@ -353,6 +353,31 @@ ZK_HD Fq2U to_u(const Fq2 &s) { return fq2u_from_sat(s); }
 ZK_HD Fq to_sat(const FqU &u) { return fqu_to_sat(u); }
 ZK_HD Fq2 to_sat(const Fq2U &u) { return fq2u_to_sat(u); }
 
+// ---- inversion (setup's batched to-affine only: one per thread per batch, never in the MSM inner loops)
+ZK_HD FqU fqu_inv(const FqU &a) {          // a^(q-2); a < 2^12 q, result < 2q
+    uint32_t e[12];
+    uint32_t borrow = 2;
+    for (int i = 0; i < 12; i++) {
+        uint64_t t = (uint64_t)FqP::mod(i) - borrow;
+        e[i] = (uint32_t)t;
+        borrow = (uint32_t)(t >> 63);
+    }
+    FqU acc = a;                             // top bit of q - 2 (bit 380) is set
+    for (int i = 379; i >= 0; i--) {
+        acc = fqu_sqr(acc);
+        if ((e[i / 32] >> (i % 32)) & 1) acc = fqu_mul(acc, a);
+    }
+    return acc;
+}
+ZK_HD FqU f_inv(const FqU &a) { return fqu_inv(a); }
+ZK_HD Fq2U f_inv(const Fq2U &a) {           // conj(a) / (c0^2 + c1^2); components of a <= 31q
+    const FqU n = fqu_inv(fqu_add(fqu_sqr(a.c0), fqu_sqr(a.c1)));
+    return Fq2U{fqu_mul(a.c0, n), fqu_mul(fqu_sub<32>(FqU::zero(), a.c1), n)};
+}
+// bring every component back below 2q (a product by one): what stored proving-key coordinates must satisfy
+ZK_HD FqU f_tidy(const FqU &a) { return a; }                 // callers pass products, already < 2q
+ZK_HD Fq2U f_tidy(const Fq2U &a) { return Fq2U{fqu_mul(a.c0, FqU::one()), fqu_mul(a.c1, FqU::one())}; }
+
 // saturated types: second-level subtraction and the mod test are the plain ones
 ZK_HD Fq f_sub2(const Fq &a, const Fq &b) { return fp_sub(a, b); }
 ZK_HD Fq2 f_sub2(const Fq2 &a, const Fq2 &b) { return f_sub(a, b); }

@@ -382,33 +382,77 @@ void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out
 }
 
 // ------------------------------------------------------------------------------------------------ fixed base
-template <class F>
-__global__ void __launch_bounds__(64) fixed_base_table_kernel(const XYZZ<F> *win_bases /*32*/, Affine<F> *table /*32*255*/) {
+// [s_i]G for many scalars (Groth16 setup, generator.rs's FixedBase::msm): 8-bit windows over a table of the 32 x 255 affine
+// multiples d * 2^(8w) * G, all arithmetic in the unsaturated form.  Sums stay in XYZZ; the conversion to affine is batched
+// (Montgomery's trick, one inversion per thread per K points) because an Fq inversion costs more than the 32 mixed adds.
+template <class FU>
+__global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
+fixed_base_table_kernel(const Affine<typename FieldTraits<FU>::Sat> *win_bases /*32*/, XYZZ<FU> *table /*32*255*/) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 32 * 255) return;
     const int w = id / 255, d = id % 255 + 1;
-    const XYZZ<F> b = ldv(win_bases + w);
-    XYZZ<F> acc = XYZZ<F>::inf();
+    const Affine<typename FieldTraits<FU>::Sat> bs = ldv(win_bases + w);
+    const Affine<FU> b{to_u(bs.x), to_u(bs.y)};
+    XYZZ<FU> acc = XYZZ<FU>::inf();
     for (int bit = 7; bit >= 0; bit--) {
         acc = xyzz_dbl(acc);
-        if ((d >> bit) & 1) xyzz_add(acc, b);
+        if ((d >> bit) & 1) xyzz_madd(acc, b, false);
     }
-    stv(table + id, xyzz_to_affine(acc));
+    stv(table + id, acc);
 }
 
-template <class F>
-__global__ void __launch_bounds__(64) fixed_base_kernel(const Affine<F> *table, const uint32_t *scalars, size_t n, Affine<F> *out) {
+template <class FU>
+__global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
+fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XYZZ<FU> *out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZ<FU> acc = XYZZ<FU>::inf();
     for (int w = 0; w < 32; w++) {
         const uint32_t d = (scalars[8 * i + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
         if (d) {
-            const Affine<F> p = ldv(table + w * 255 + (d - 1));
+            const Affine<FU> p = ldv(table + w * 255 + (d - 1));
             xyzz_madd(acc, p, false);
         }
     }
-    stv(out + i, xyzz_to_affine(acc));
+    stv(out + i, acc);
+}
+
+// XYZZ -> affine for n points; thread t owns points t, t + T, t + 2T, ... (T = threads launched) so that a wave touches
+// neighbouring points at every step.  `pref` is n field elements of scratch.  Either output may be null:
+// out_u = unsaturated (device-resident key), out_sat = arkworks' saturated Montgomery form (host-bound).
+template <class FU>
+__global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
+batch_affine_kernel(const XYZZ<FU> *pts, size_t n, FU *pref, Affine<FU> *out_u, Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+    using FS = typename FieldTraits<FU>::Sat;
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    FU acc = FU::one();
+    size_t last = t;
+    for (size_t i = t; i < n; i += T) {
+        const XYZZ<FU> p = ldv(pts + i);
+        pref[i] = acc;
+        if (!p.is_inf()) acc = f_mul(acc, f_mul(p.zz, p.zzz));
+        last = i;
+    }
+    FU inv = f_inv(acc);
+    for (size_t i = last;; i -= T) {
+        const XYZZ<FU> p = ldv(pts + i);
+        Affine<FU> o = Affine<FU>::inf();
+        if (!p.is_inf()) {
+            const FU dinv = f_mul(inv, pref[i]);                  // (zz * zzz)^-1
+            inv = f_mul(inv, f_mul(p.zz, p.zzz));
+            o.x = f_tidy(f_mul(p.x, f_mul(dinv, p.zzz)));         // X / ZZ
+            o.y = f_tidy(f_mul(p.y, f_mul(dinv, p.zz)));          // Y / ZZZ
+        }
+        if (out_u) stv(out_u + i, o);
+        if (out_sat) {
+            Affine<FS> os = Affine<FS>::inf();
+            if (!p.is_inf()) os = Affine<FS>{to_sat(o.x), to_sat(o.y)};
+            stv(out_sat + i, os);
+        }
+        if (i < T + t) break;       // i == t: first point of this thread
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host drivers
@@ -613,24 +657,53 @@ void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t
     ZK_HIP(hipGetLastError());
 }
 
-template <class F>
-static void fixed_base_run(zkg16_ctx *ctx, const Affine<F> &base, const Fr *scalars_canonical, size_t n, Affine<F> *out) {
-    if (n == 0) return;
-    std::vector<XYZZ<F>> wb(32);
-    XYZZ<F> cur = XYZZ<F>::from_affine(base);
-    for (int w = 0; w < 32; w++) {
-        wb[w] = cur;
-        for (int q = 0; q < 8; q++) cur = xyzz_dbl(cur);
-    }
-    DevBuf d_wb(32 * sizeof(XYZZ<F>)), d_tab(32 * 255 * sizeof(Affine<F>));
-    ZK_HIP(hipMemcpyAsync(d_wb.p, wb.data(), 32 * sizeof(XYZZ<F>), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(fixed_base_table_kernel<F>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<XYZZ<F>>(), d_tab.as<Affine<F>>());
-    hipLaunchKernelGGL(fixed_base_kernel<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_tab.as<Affine<F>>(),
-                       reinterpret_cast<const uint32_t *>(scalars_canonical), n, out);
+template <class FU>
+static void batch_affine_run(zkg16_ctx *ctx, const XYZZ<FU> *pts, size_t n, DevBuf &pref, Affine<FU> *out_u,
+                             Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+    // about one wave per SIMD: the serial inversion (~600 products) is amortised over n / threads points
+    size_t threads = (size_t)ctx->num_cus * 4 * 64;
+    if (threads * 4 > n) threads = (n + 3) / 4;
+    const unsigned blocks = (unsigned)((threads + 63) / 64);
+    pref.ensure(n * sizeof(FU));
+    hipLaunchKernelGGL(batch_affine_kernel<FU>, dim3(blocks), dim3(64), 0, ctx->stream, pts, n, pref.as<FU>(), out_u, out_sat);
     ZK_HIP(hipGetLastError());
+}
+
+// out_u / out_sat: device pointers, either may be null
+template <class FU>
+static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<typename FieldTraits<FU>::Sat> &base, const Fr *scalars_canonical,
+                           size_t n, Affine<FU> *out_u, Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+    using FS = typename FieldTraits<FU>::Sat;
+    if (n == 0) return;
+    if (cache.key.size() != sizeof base || memcmp(cache.key.data(), &base, sizeof base) != 0) {
+        std::vector<Affine<FS>> wb(32);
+        XYZZ<FS> cur = XYZZ<FS>::from_affine(base);
+        for (int w = 0; w < 32; w++) {
+            wb[w] = xyzz_to_affine(cur);
+            for (int q = 0; q < 8; q++) cur = xyzz_dbl(cur);
+        }
+        DevBuf d_wb(32 * sizeof(Affine<FS>)), d_xyzz(32 * 255 * sizeof(XYZZ<FU>));
+        cache.table.ensure(32 * 255 * sizeof(Affine<FU>));
+        ZK_HIP(hipMemcpyAsync(d_wb.p, wb.data(), 32 * sizeof(Affine<FS>), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
+                           d_xyzz.as<XYZZ<FU>>());
+        ZK_HIP(hipGetLastError());
+        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, cache.table.as<Affine<FU>>(), nullptr);
+        ZK_HIP(hipStreamSynchronize(ctx->stream));      // d_wb, d_xyzz go out of scope
+        cache.key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
+    }
+    cache.sums.ensure(n * sizeof(XYZZ<FU>));
+    hipLaunchKernelGGL(fixed_base_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cache.table.as<Affine<FU>>(),
+                       reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>());
+    ZK_HIP(hipGetLastError());
+    batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, out_u, out_sat);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
-void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, G1Affine *out) { fixed_base_run<Fq>(ctx, base, sc, n, out); }
-void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, G2Affine *out) { fixed_base_run<Fq2>(ctx, base, sc, n, out); }
+void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, G1Affine *out_sat, G1AffineU *out_u) {
+    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, out_u, out_sat);
+}
+void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, G2Affine *out_sat, G2AffineU *out_u) {
+    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, out_u, out_sat);
+}
 
 }  // namespace zk

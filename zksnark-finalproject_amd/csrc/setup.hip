@@ -115,14 +115,13 @@ static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont,
                       G1AffineU *resident = nullptr) {
     if (!n) return;
     canon.ensure(n * sizeof(Fr));
-    pts.ensure(n * sizeof(G1Affine));
     fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
-    fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, pts.as<G1Affine>());
     if (resident) {                                   // key stays on the device: straight into the unsaturated pk layout
-        convert_g1_bases(ctx, pts.as<G1Affine>(), resident, n);
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, nullptr, resident);
         return;
     }
+    pts.ensure(n * sizeof(G1Affine));
+    fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, pts.as<G1Affine>());
     ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (inf) {
@@ -134,14 +133,13 @@ static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont,
                       G2AffineU *resident = nullptr) {
     if (!n) return;
     canon.ensure(n * sizeof(Fr));
-    pts.ensure(n * sizeof(G2Affine));
     fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
-    fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, pts.as<G2Affine>());
     if (resident) {
-        convert_g2_bases(ctx, pts.as<G2Affine>(), resident, n);
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, nullptr, resident);
         return;
     }
+    pts.ensure(n * sizeof(G2Affine));
+    fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, pts.as<G2Affine>());
     ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (inf) {
