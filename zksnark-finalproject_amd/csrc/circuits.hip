@@ -12,11 +12,13 @@
 // (square-and-multiply from the MSB starting at the constant 1: x^17 = 4 squarings + 1 product = 5 constraints),
 // `enforce_equal` ((a - b) * 1 = 0) and `mul_equals` (a * b = c).  Matrices are exported as CSR with the instance
 // variables first (ark `ConstraintMatrices`).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <memory>
 #include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/zkg16.h"
@@ -44,6 +46,10 @@ typedef uint32_t VarId;
 const VarId WIT = 0x80000000u;
 
 struct Term { VarId v; Fr c; };
+
+// false while a Poseidon permutation is replayed from a template (permute_gadget): values, witness allocation and the
+// is_const flags follow the normal code path, term vectors and constraint rows are filled in from the template afterwards
+static thread_local bool g_terms = true;
 
 // An FpVar: a linear combination over variables (sorted by id) together with its value.  Constants are LCs over the
 // One variable only (`is_const`), mirroring FpVar::Constant.
@@ -84,13 +90,16 @@ struct Circuit {
     Lc new_witness(const Fr &v) {
         witness.push_back(v);
         Lc r;
-        r.t.push_back(Term{WIT | (VarId)(witness.size() - 1), Fr::one()});
+        if (g_terms) r.t.push_back(Term{WIT | (VarId)(witness.size() - 1), Fr::one()});
         r.val = v;
         r.is_const = false;
         return r;
     }
     static Lc add(const Lc &a, const Lc &b) {
         Lc r;
+        r.val = fp_add(a.val, b.val);
+        r.is_const = a.is_const && b.is_const;
+        if (!g_terms) return r;
         r.t.reserve(a.t.size() + b.t.size());
         size_t i = 0, j = 0;
         while (i < a.t.size() || j < b.t.size()) {
@@ -102,21 +111,64 @@ struct Circuit {
                 i++; j++;
             }
         }
-        r.val = fp_add(a.val, b.val);
-        r.is_const = a.is_const && b.is_const;
         return r;
+    }
+    // a += c * One, in place (the One variable has id 0, so its term is always first)
+    static void add_const(Lc &a, const Fr &c) {
+        if (c.is_zero()) return;
+        a.val = fp_add(a.val, c);
+        if (!g_terms) return;
+        if (!a.t.empty() && a.t[0].v == 0) {
+            a.t[0].c = fp_add(a.t[0].c, c);
+            if (a.t[0].c.is_zero()) a.t.erase(a.t.begin());
+        } else {
+            a.t.insert(a.t.begin(), Term{0, c});
+        }
+    }
+    // out[i] = sum_j m[i][j] * in[j], i, j < 3: one three-way merge instead of nine scales and nine pairwise merges
+    static void mix3(const Lc in[3], const Fr m[3][3], Lc out[3]) {
+        size_t k[3] = {0, 0, 0};
+        const size_t cap = in[0].t.size() + in[1].t.size() + in[2].t.size();
+        for (int i = 0; i < 3; i++) {
+            out[i].t.clear();
+            out[i].t.reserve(cap);
+            out[i].val = fp_add(fp_add(fp_mul(m[i][0], in[0].val), fp_mul(m[i][1], in[1].val)), fp_mul(m[i][2], in[2].val));
+            out[i].is_const = in[0].is_const && in[1].is_const && in[2].is_const;
+        }
+        if (!g_terms) return;
+        for (;;) {
+            VarId v = 0xffffffffu;
+            bool any = false;
+            for (int j = 0; j < 3; j++)
+                if (k[j] < in[j].t.size()) {
+                    any = true;
+                    if (in[j].t[k[j]].v < v) v = in[j].t[k[j]].v;
+                }
+            if (!any) break;
+            Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+            for (int j = 0; j < 3; j++)
+                if (k[j] < in[j].t.size() && in[j].t[k[j]].v == v) {
+                    const Fr &c = in[j].t[k[j]].c;
+                    for (int i = 0; i < 3; i++) acc[i] = fp_add(acc[i], fp_mul(m[i][j], c));
+                    k[j]++;
+                }
+            for (int i = 0; i < 3; i++)
+                if (!acc[i].is_zero()) out[i].t.push_back(Term{v, acc[i]});
+        }
     }
     static Lc scale(const Lc &a, const Fr &c) {
         Lc r;
         if (c.is_zero()) { r.is_const = true; return r; }
-        r.t.reserve(a.t.size());
-        for (const Term &x : a.t) r.t.push_back(Term{x.v, fp_mul(x.c, c)});
         r.val = fp_mul(a.val, c);
         r.is_const = a.is_const;
+        if (!g_terms) return r;
+        r.t.reserve(a.t.size());
+        for (const Term &x : a.t) r.t.push_back(Term{x.v, fp_mul(x.c, c)});
         return r;
     }
     static Lc sub(const Lc &a, const Lc &b) { return add(a, scale(b, fp_neg(Fr::one()))); }
     void enforce(const Lc &a, const Lc &b, const Lc &c) {
+        if (!g_terms) return;
         rows[0].push(a.t);
         rows[1].push(b.t);
         rows[2].push(c.t);
@@ -212,31 +264,129 @@ Fr poseidon_hash_native(const Fr *elems, size_t n) {
     return st[POSEIDON_CAP];
 }
 // the same through the gadget (PoseidonSpongeVar): returns state[1] as an FpVar
-void permute_gadget(Circuit &cs, Lc st[3]) {
+void permute_gadget_generic(Circuit &cs, Lc st[3]) {
     const PoseidonParams &p = pparams();
     for (int r = 0; r < P_ROUNDS; r++) {
-        for (int i = 0; i < 3; i++) st[i] = Circuit::add(st[i], cs.constant(p.ark[r][i]));
+        for (int i = 0; i < 3; i++) Circuit::add_const(st[i], p.ark[r][i]);
         const bool full = r < P_HALF || r >= P_HALF + POSEIDON_PARTIAL;
         if (full) for (int i = 0; i < 3; i++) st[i] = cs.pow_by_constant(st[i], POSEIDON_ALPHA);
         else st[0] = cs.pow_by_constant(st[0], POSEIDON_ALPHA);
         Lc n[3];
-        for (int i = 0; i < 3; i++) {
-            Lc cur = cs.constant(Fr::zero());
-            for (int j = 0; j < 3; j++) cur = Circuit::add(cur, Circuit::scale(st[j], p.mds[i][j]));
-            n[i] = cur;
+        Circuit::mix3(st, p.mds, n);
+        for (int i = 0; i < 3; i++) st[i].t.swap(n[i].t), st[i].val = n[i].val, st[i].is_const = n[i].is_const;
+    }
+}
+
+// Every permutation of a sponge after the first sees the same *shape* of input state (the same coefficients on a
+// different set of variables), so its ~265 constraint rows are the first one's with the variable ids renamed.  The rows of
+// the first permutation of each shape are kept as a template over "slots" (the distinct input variables in id order, then
+// the witnesses the permutation allocates, in allocation order); later permutations run the generic code for values and
+// witness allocation only and copy the rows.  Renaming is order-preserving (slots are ranked by id and new witnesses are
+// larger than everything before them), so rows stay sorted by column exactly as the generic path leaves them.
+struct PermTemplate {
+    std::vector<uint32_t> shape;    // per state LC: #terms, is_const, then the slot of every term
+    std::vector<Fr> coeff;          // the coefficients in the same order
+    bool slot0_is_one = false;
+    uint32_t n_slots = 0, n_new = 0;
+    std::vector<uint32_t> ptr[3];   // rows as CSR over template ids (slot, or n_slots + new-witness index)
+    std::vector<Term> t[3];
+    std::vector<Term> out[3];
+    bool out_const[3] = {false, false, false};
+};
+struct PermTemplates {
+    std::vector<PermTemplate> list;
+    bool enabled = true;
+};
+
+static void state_signature(const Lc st[3], std::vector<VarId> &ids, std::vector<uint32_t> &shape, std::vector<Fr> &coeff) {
+    ids.clear(); shape.clear(); coeff.clear();
+    ids.push_back(0);       // the One variable is always slot 0: round constants put it into rows whether or not the state has it
+    for (int i = 0; i < 3; i++)
+        for (const Term &x : st[i].t) ids.push_back(x.v);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    for (int i = 0; i < 3; i++) {
+        shape.push_back((uint32_t)st[i].t.size());
+        shape.push_back(st[i].is_const ? 1u : 0u);
+        for (const Term &x : st[i].t) {
+            shape.push_back((uint32_t)(std::lower_bound(ids.begin(), ids.end(), x.v) - ids.begin()));
+            coeff.push_back(x.c);
         }
-        for (int i = 0; i < 3; i++) st[i] = n[i];
+    }
+}
+
+void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
+    if (!tpls.enabled) { permute_gadget_generic(cs, st); return; }
+    std::vector<VarId> ids;
+    std::vector<uint32_t> shape;
+    std::vector<Fr> coeff;
+    state_signature(st, ids, shape, coeff);
+    const bool one0 = true;     // see state_signature
+    const PermTemplate *hit = nullptr;
+    for (const PermTemplate &t : tpls.list)
+        if (t.slot0_is_one == one0 && t.shape == shape && t.coeff.size() == coeff.size() &&
+            memcmp(t.coeff.data(), coeff.data(), coeff.size() * sizeof(Fr)) == 0) { hit = &t; break; }
+    const size_t w0 = cs.witness.size();
+    if (!hit) {
+        size_t r0[3], k0[3];
+        for (int m = 0; m < 3; m++) { r0[m] = cs.rows[m].size(); k0[m] = cs.rows[m].t.size(); }
+        permute_gadget_generic(cs, st);
+        PermTemplate t;
+        t.shape = shape; t.coeff = coeff; t.slot0_is_one = one0;
+        t.n_slots = (uint32_t)ids.size();
+        t.n_new = (uint32_t)(cs.witness.size() - w0);
+        bool ok = true;
+        auto to_tpl = [&](VarId v) -> VarId {
+            if ((v & WIT) && (v & ~WIT) >= w0) return t.n_slots + (VarId)((v & ~WIT) - w0);
+            auto it = std::lower_bound(ids.begin(), ids.end(), v);
+            if (it == ids.end() || *it != v) { ok = false; return 0; }     // a variable from outside the state: not replayable
+            return (VarId)(it - ids.begin());
+        };
+        for (int m = 0; m < 3; m++) {
+            const Circuit::Rows &R = cs.rows[m];
+            t.ptr[m].push_back(0);
+            for (size_t r = r0[m]; r < R.size(); r++) {
+                for (uint64_t k = R.ptr[r]; k < R.ptr[r + 1]; k++) t.t[m].push_back(Term{to_tpl(R.t[k].v), R.t[k].c});
+                t.ptr[m].push_back((uint32_t)t.t[m].size());
+            }
+            (void)k0;
+        }
+        for (int i = 0; i < 3; i++) {
+            for (const Term &x : st[i].t) t.out[i].push_back(Term{to_tpl(x.v), x.c});
+            t.out_const[i] = st[i].is_const;
+        }
+        if (ok && tpls.list.size() < 16) tpls.list.push_back(std::move(t));
+        return;
+    }
+    g_terms = false;
+    permute_gadget_generic(cs, st);
+    g_terms = true;
+    if (cs.witness.size() - w0 != hit->n_new) throw std::logic_error("poseidon template: witness count mismatch");
+    auto from_tpl = [&](VarId v) -> VarId { return v < hit->n_slots ? ids[v] : (WIT | (VarId)(w0 + (v - hit->n_slots))); };
+    for (int m = 0; m < 3; m++) {
+        Circuit::Rows &R = cs.rows[m];
+        const uint64_t base = R.t.size();
+        for (const Term &x : hit->t[m]) R.t.push_back(Term{from_tpl(x.v), x.c});
+        for (size_t r = 1; r < hit->ptr[m].size(); r++) R.ptr.push_back(base + hit->ptr[m][r]);
+    }
+    for (int i = 0; i < 3; i++) {
+        st[i].t.clear();
+        for (const Term &x : hit->out[i]) st[i].t.push_back(Term{from_tpl(x.v), x.c});
+        if (st[i].is_const != hit->out_const[i]) throw std::logic_error("poseidon template: state flag mismatch");
     }
 }
 Lc poseidon_hash_gadget(Circuit &cs, const std::vector<Lc> &elems) {
+    PermTemplates tpls;
+    const char *env = getenv("ZKG16_SYNTH_GENERIC");       // tests: force the plain path to compare against
+    tpls.enabled = !(env && env[0] == '1');
     Lc st[3] = {cs.constant(Fr::zero()), cs.constant(Fr::zero()), cs.constant(Fr::zero())};
     size_t pos = 0;
     for (const Lc &e : elems) {
-        if (pos == POSEIDON_RATE) { permute_gadget(cs, st); pos = 0; }
+        if (pos == POSEIDON_RATE) { permute_gadget(cs, tpls, st); pos = 0; }
         st[POSEIDON_CAP + pos] = Circuit::add(st[POSEIDON_CAP + pos], e);
         pos++;
     }
-    permute_gadget(cs, st);
+    permute_gadget(cs, tpls, st);
     return st[POSEIDON_CAP];
 }
 
@@ -319,8 +469,13 @@ int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_c
         Lc in_c = cs.new_input(hash_c);
         cs.enforce_equal(hc, in_c);
     } catch (const std::bad_alloc &) {
+        g_terms = true;
         delete c;
         return ZKG16_ERR_OOM;
+    } catch (const std::exception &) {      // a template replay that did not line up: a bug, never a property of the input
+        g_terms = true;
+        delete c;
+        return ZKG16_ERR_UNSUPPORTED;
     }
     *out = c;
     return ZKG16_OK;
