@@ -9,7 +9,11 @@ matrices and the full assignment already resident in HBM (zkg16_prove_resident).
 BASELINE.json configs[1]: matrix-mul 32x32 + Poseidon circuit shape (472,564 constraints, domain 2^19).
 N>1: index-range sharded proving key (every rank recomputes h, runs the five MSMs over its 1/N of the bases),
 ONE exchange per proof — an all_gather of 72 u64 of partial sums over RCCL — and the tail on every rank:
-strong scaling of one proof, as BASELINE.json's north_star asks.
+strong scaling of one proof, as BASELINE.json's north_star asks (`--parallel replicas` is the throughput alternative:
+every rank proves its own proofs on the whole key, no exchange, weak scaling).
+
+At N=1 the line also carries `throughput_in_flight`: after the contract's timed region, the same proofs with
+`--in-flight` (default 2) of them in flight at once, one library ctx per host thread — what a multi-worker server gets.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate_g1) from HIP-event pairs
 recorded on the library's stream during the timed region; `cpu_baseline` times the CPU oracle (a port, see
@@ -39,6 +43,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: several ranks on one GPU)")
     ap.add_argument("--cpu-sample-n", type=int, default=12, help="matrix size of the bounded CPU-baseline sample")
+    ap.add_argument("--parallel", default="shard", choices=["shard", "replicas"],
+                    help="N > 1: shard = one proof's index ranges over the ranks (north_star; strong scaling); "
+                         "replicas = every rank proves its own proofs on the whole key (no exchange; weak scaling)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="N = 1: after the contract's timed region, also report throughput with this many proofs in flight "
+                         "(one ctx per host thread, as one ctx per server worker would run); 0/1 = skip")
     return ap.parse_args()
 
 
@@ -145,20 +155,26 @@ def main():
         r1cs, z = circ.r1cs, circ.z
         shp = dict(n=n, nc=circ.num_constraints, num_instance=circ.num_instance, num_witness=circ.num_witness,
                    num_vars=circ.num_vars, domain=circ.domain)
+    sharded = world > 1 and args.parallel == "shard"
     pk = make_key(dev, r1cs, shp, seed=0xC0FFEE)
-    ph = dev.pk_load(pk, shp["num_instance"], shard_index=rank, shard_count=world)
+    ph = dev.pk_load(pk, shp["num_instance"], shard_index=rank if sharded else 0, shard_count=world if sharded else 1)
     rh = dev.r1cs_load(r1cs, shp["num_vars"])
     wh = dev.witness_load(z)
+    extra = []                       # further contexts on the same GPU for the proofs-in-flight leg
+    if world == 1 and args.in_flight > 1:
+        for _ in range(args.in_flight - 1):
+            d2 = Device(dev_index)
+            extra.append((d2, d2.pk_load(pk, shp["num_instance"]), d2.r1cs_load(r1cs, shp["num_vars"]), d2.witness_load(z)))
     del pk
     rng = np.random.default_rng(99)
     rs = [(rand_fr_mont(rng), rand_fr_mont(rng)) for _ in range(args.steps + args.warmup)]
 
     xdev = "cuda" if on_gpu else "cpu"
-    if world > 1:
+    if sharded:
         gather_buf = [torch.empty(77, dtype=torch.int64, device=xdev) for _ in range(world)]
 
     def one_proof(r, s):
-        if world == 1:
+        if not sharded:
             return dev.prove_resident(ph, rh, wh, r, s)
         part, pinf = dev.prove_partial(ph, rh, wh, r, s)
         rec = np.concatenate([part.view(np.int64), pinf.astype(np.int64)])
@@ -190,14 +206,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    stages = dev.last_timings()
+    in_flight = None
+    if extra:
+        import threading
+        lanes = [(dev, ph, rh, wh)] + extra
+        per = max(args.steps, 4)
+
+        def lane_work(lane, count):
+            d, p_, r_, w_ = lane
+            for j in range(count):
+                d.prove_resident(p_, r_, w_, *rs[j % len(rs)])
+        for lane in lanes[1:]:
+            lane_work(lane, 1)
+        ths = [threading.Thread(target=lane_work, args=(lane, per)) for lane in lanes]
+        barrier()
+        t1 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        in_flight = {"proofs_in_flight": len(lanes), "proofs": per * len(lanes), "value": per * len(lanes) / dt2, "unit": "proofs/s",
+                     "ms_per_proof": dt2 / (per * len(lanes)) * 1e3,
+                     "note": "same GPU, one library ctx (own streams + workspaces) per host thread; outside the contract's timed region"}
+        for d2, *_ in extra:
+            d2.close()
+
     if rank == 0:
-        stages = dev.last_timings()
+        total_proofs = args.steps * (world if (world > 1 and not sharded) else 1)
         acc = dev.kernel_stats("msm_accumulate_g1")
         acc2 = dev.kernel_stats("msm_accumulate_g2")
         # algorithmic bytes of one G1 bucket-accumulation launch: every (base, scalar) term once = (96 + 32) B per term
         # (SURVEY.md 8d); terms per launch = MSM length of that launch, averaged over the 4 G1 MSMs of a proof.
-        nz = (shp["num_vars"] + 3 + world - 1) // world
-        nh = (shp["domain"] - 1 + world - 1) // world
+        nshard = world if sharded else 1
+        nz = (shp["num_vars"] + 3 + nshard - 1) // nshard
+        nh = (shp["domain"] - 1 + nshard - 1) // nshard
         terms_per_launch = (3 * nz + nh) / 4.0
         alg_bytes = 128.0 * terms_per_launch
         avg_ms = acc["ms"] / max(acc["launches"], 1)
@@ -207,9 +252,9 @@ def main():
         # only known for the default workload on one GPU
         traffic = 1.05e9 if (world == 1 and args.matrix_n == 32 and args.workload == "matrix") else None
         out = {
-            "metric": "groth16_proofs_per_sec", "value": args.steps / dt, "unit": "proofs/s",
+            "metric": "groth16_proofs_per_sec", "value": total_proofs / dt, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": ("Fermat-prime-shaped boolean circuit (BASELINE configs[4] shape, synthetic rows): %d constraints, %d witness vars, domain 2^%d; "
                                     "pk/R1CS/assignment resident in HBM" % (shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1))
@@ -218,8 +263,10 @@ def main():
                                    "pk/R1CS/assignment resident in HBM; %s; structurally faithful random-point key"
                                    % (args.matrix_n, args.matrix_n, shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1,
                                       "synthetic shape-exact rows" if args.synthetic_rows else "R1CS + witness synthesized by the C++ mirror of the reference's MatrixCircuit on all-ones inputs"),
-                       "parallelism": "1 GPU" if world == 1 else "index-range sharded pk over %d GPUs + 1 all_gather(77 words)/proof" % world},
-            "constraints_per_sec": shp["nc"] * args.steps / dt,
+                       "parallelism": "1 GPU" if world == 1 else
+                                      ("index-range sharded pk over %d GPUs + 1 all_gather(77 words)/proof" % world if sharded else
+                                       "%d replicas: every GPU proves its own proofs on the whole key, no exchange" % world)},
+            "constraints_per_sec": shp["nc"] * total_proofs / dt,
             "stage_ms_last_proof": stages,
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_g1", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
@@ -229,6 +276,8 @@ def main():
                                  "instructions) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command "
                                  "(bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
+        if in_flight:
+            out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, shp["nc"], min(os.cpu_count() or 1, 16))
         print(json.dumps(out), flush=True)
