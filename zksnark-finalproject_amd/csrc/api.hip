@@ -187,6 +187,18 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     }
     ZK_HIP(hipEventRecord(ev[1], ctx->stream));
 
+    const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
+    MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
+    const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
+    // ---- the four z-side accumulations go onto the main stream BEFORE the witness map's ~40 launches (G2 first: its long
+    // reduction then hides behind the G1 accumulations); their reductions — whose first packet is a wait — only after those
+    // launches (msm_enqueue_reduce).  Kernel trace at n = 32: queued after the witness map, the G2 accumulation started
+    // 2.0 ms into the proof with its inputs ready at 0.6 ms.
+    msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+    msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
+    msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
+    msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
     // z-side work (measured in one process, n = 32: 18.15 vs 18.58 ms in order; n = 12: 10.05 vs 11.16 ms)
     const bool wm_concurrent = ctx->opt_wm_concurrent != 0;
@@ -197,7 +209,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
         ZK_HIP(hipEventRecord(ev[3], ctx->stream));
         if (nh) fr_from_mont_run(ctx, h + pk.h_lo, hs, nh);
-        msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h);
+        msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h, ctx->opt_window_bits_h);
         ZK_HIP(hipEventRecord(ev[4], ctx->stream));
     } catch (...) {
         if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
@@ -205,17 +217,18 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     }
     if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
 
-    // ---- queue the five MSMs: accumulations on the main stream (G2 first: its long reduction then hides behind the G1
-    // accumulations; H last: it is the only one that waits for the witness map), reductions on the aux stream; then collect —
-    // each MSM's host Horner overlaps the device work still queued behind it
-    MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
-    const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
-    msm_g2_enqueue(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
-    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
-    msm_g1_enqueue(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
-    msm_g1_enqueue(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    msm_g2_enqueue_reduce(ctx, ctx->slots[0]);
+    msm_g1_enqueue_reduce(ctx, ctx->slots[2]);
+    msm_g1_enqueue_reduce(ctx, ctx->slots[3]);
+    msm_g1_enqueue_reduce(ctx, ctx->slots[4]);
+    if (trace) fprintf(stderr, "host: z-side msms queued at %.3f ms\n", now_ms() - t0);
+
+    // ---- H last: it is the only MSM that waits for the witness map; then collect — each MSM's host Horner overlaps the
+    // device work still queued behind it
+    if (trace) fprintf(stderr, "host: witness map queued at %.3f ms\n", now_ms() - t0);
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
     msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
+    if (trace) fprintf(stderr, "host: h queued at %.3f ms\n", now_ms() - t0);
     double tprev = now_ms();
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
     out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
@@ -359,12 +372,10 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
         hipDeviceProp_t prop;
         ZK_HIP(hipGetDeviceProperties(&prop, dev));
         ctx->num_cus = prop.multiProcessorCount;
-        // priorities: the short, latency-bound chains (witness map / sorts, fix-ups / reductions) go ahead of the long
-        // throughput-bound accumulations whenever both have work queued
-        int prio_lo = 0, prio_hi = 0;
-        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));      // lo = least priority (numerically largest)
-        ZK_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo));
-        ZK_HIP(hipStreamCreateWithPriority(&ctx->wm_stream, hipStreamNonBlocking, prio_hi));
+        // Plain (equal-priority) streams.  Measured at n = 32: main low / witness-map high priority 16.6 ms per proof,
+        // reversed 16.2 ms, no priorities 15.0 ms (profiles/kernel_timeline_r1_*.txt).
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->wm_stream, hipStreamNonBlocking));
     } catch (const HipError &e) {
         int rc = fail(ctx, e);
         delete ctx;
@@ -408,6 +419,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "window_bits")) {
         if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "window_bits_h")) {
+        if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_window_bits_h = (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "wm_concurrent")) {      // -1 auto (default), 0 in-order, 1 third stream

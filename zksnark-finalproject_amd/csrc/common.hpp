@@ -105,6 +105,9 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
     hipEvent_t acc_done = nullptr, red_done = nullptr;
     int nwin = 0, c = 0;
     bool active = false;
+    bool pending_reduce = false;    // accumulation queued, reduction not yet (msm_*_enqueue_reduce)
+    void *red_buckets = nullptr;
+    size_t red_nb = 0;
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
@@ -133,6 +136,7 @@ struct zkg16_ctx {
     std::map<std::string, zk::KernelStat> kstats;
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
+    int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
     int num_cus = 256;
@@ -173,7 +177,7 @@ struct MsmPlan {
     size_t total_entries = 0;            // upper bound n * windows (the exact count lives on the device)
     uint32_t lanes_g1 = 0, lanes_g2 = 0; // lanes of one resident round of accumulation waves (2 / 1 waves per SIMD)
 };
-void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan);
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan, int window_bits = 0);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
 void radix_sort_hi32(zkg16_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, unsigned key_bits, DevBuf &temp, const char *timer_name);
 // setup.hip: Groth16 key generation from a known trapdoor (discrete logs on device, then fixed-base batches)
@@ -185,6 +189,11 @@ struct SetupOut {
 void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out, PkDev *resident = nullptr);
 void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
+// the two halves of an enqueue, for callers that interleave other launches between them (prove_device)
+void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
+void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);
+void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot);
+void msm_g2_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot);
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
 void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);
 G1XYZZ msm_g1_collect(zkg16_ctx *ctx, MsmSlot &slot);

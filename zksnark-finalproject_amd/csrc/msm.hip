@@ -469,9 +469,9 @@ static int pick_window_bits(zkg16_ctx *ctx, size_t n) {
     return c;
 }
 
-void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan) {
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan, int window_bits) {
     plan.n = n;
-    plan.c = pick_window_bits(ctx, n);
+    plan.c = (window_bits >= 2 && window_bits <= 16) ? window_bits : pick_window_bits(ctx, n);
     plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
     plan.nb = (size_t)1 << (plan.c - 1);
     plan.total_entries = 0;
@@ -512,10 +512,21 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 //   main stream: clear buckets -> accumulate -> fix-ups                      -> event acc_done
 //   aux  stream: wait acc_done -> reduction -> convert window sums -> D2H   -> event red_done
 //   host       : wait red_done -> Horner over the window sums (msm_collect)
+// bucket clears go through an ordinary kernel on the MSM's own stream (not hipMemsetAsync)
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *p, size_t n16, uint32_t *also) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
+    if (i == 0 && also) *also = 0;
+}
+static void zero_fill(hipStream_t st, void *p, size_t bytes, uint32_t *also) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4 *>(p), n16, also);
+}
+
 template <class F>
-static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot) {
-    using FS = typename FieldTraits<F>::Sat;
+static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot) {
     slot.active = false;
+    slot.pending_reduce = false;
     slot.nwin = plan.nwin;
     slot.c = plan.c;
     if (plan.n == 0) return;
@@ -531,7 +542,8 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     slot.seg_head.ensure(nseg * psz);
     slot.seg_tail.ensure(nseg * psz);
     slot.seg_meta.ensure(nseg * 2 * sizeof(int32_t));
-    ZK_HIP(hipMemsetAsync(slot.buckets.p, 0, tb * psz, ctx->stream));
+    slot.long_list.ensure((nseg + 1) * sizeof(uint32_t));
+    zero_fill(ctx->stream, slot.buckets.p, tb * psz, slot.long_list.as<uint32_t>());      // + the long-fix-up counter
     AccArgs<F> a;
     a.bases = bases;
     a.entries = ws.entries.as<uint2>();
@@ -551,9 +563,7 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     {
         // fix-ups stay on the main stream: measured faster than moving them behind the reductions on the aux stream
         hipStream_t fs = ctx->stream;
-        slot.long_list.ensure((nseg + 1) * sizeof(uint32_t));
         uint32_t *long_list = slot.long_list.as<uint32_t>() + 1, *long_count = slot.long_list.as<uint32_t>();
-        ZK_HIP(hipMemsetAsync(long_count, 0, sizeof(uint32_t), fs));
         {
             ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)nseg, fs);
             hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, fs, a, long_list, long_count);
@@ -570,10 +580,26 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(slot.acc_done, ctx->stream));
+    slot.red_buckets = a.buckets;
+    slot.red_nb = plan.nb;
+    slot.pending_reduce = true;
+}
 
-    // ---- this slot's own stream: the weighted bucket reduction, while the main stream already runs the next MSM's
-    // accumulation; the five reductions of a proof are latency-bound chains on a few hundred waves each, so they also run
-    // concurrently with each other
+// ---- this slot's own stream: the weighted bucket reduction, while the main stream already runs the next MSM's
+// accumulation; the five reductions of a proof are latency-bound chains on a few hundred waves each, so they also run
+// concurrently with each other.  Queued separately from the accumulation: its first packet is a wait on acc_done, and
+// HIP multiplexes streams onto a few hardware queues, so a wait queued early parks whatever is queued behind it.
+template <class F>
+static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
+    using FS = typename FieldTraits<F>::Sat;
+    if (!slot.pending_reduce) return;
+    slot.pending_reduce = false;
+    MsmPlan plan;
+    plan.nb = slot.red_nb;
+    plan.nwin = slot.nwin;
+    const size_t tb = plan.nb * plan.nwin;
+    const size_t psz = sizeof(XYZZ<F>);
+    struct { XYZZ<F> *buckets; } a{reinterpret_cast<XYZZ<F> *>(slot.red_buckets)};
     hipStream_t aux = slot.stream;
     ZK_HIP(hipStreamWaitEvent(aux, slot.acc_done, 0));
     const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
@@ -614,6 +640,11 @@ static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, c
     ZK_HIP(hipEventRecord(slot.red_done, aux));
     slot.active = true;
 }
+template <class F>
+static void msm_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot) {
+    msm_enqueue_acc<F>(ctx, ws, plan, bases, slot);
+    msm_enqueue_reduce<F>(ctx, slot);
+}
 
 template <class FS>
 static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
@@ -631,6 +662,10 @@ static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
     return total;
 }
 
+void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot) { msm_enqueue_acc<FqU>(ctx, ws, plan, bases, slot); }
+void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot) { msm_enqueue_acc<Fq2U>(ctx, ws, plan, bases, slot); }
+void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) { msm_enqueue_reduce<FqU>(ctx, slot); }
+void msm_g2_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) { msm_enqueue_reduce<Fq2U>(ctx, slot); }
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot) { msm_enqueue<FqU>(ctx, ws, plan, bases, slot); }
 void msm_g2_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot) { msm_enqueue<Fq2U>(ctx, ws, plan, bases, slot); }
 G1XYZZ msm_g1_collect(zkg16_ctx *ctx, MsmSlot &slot) { return msm_collect<Fq>(ctx, slot); }
