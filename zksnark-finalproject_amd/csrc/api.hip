@@ -421,6 +421,15 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_window_bits = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "g1_waves")) {
+        if (value < 0 || value > 4) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_g1_waves = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "fixup_aux")) {
+        ctx->opt_fixup_aux = value ? 1 : 0;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "window_bits_h")) {
         if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits_h = (int)value;

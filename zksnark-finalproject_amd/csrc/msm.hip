@@ -499,7 +499,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     // the exact entry count stays on the device (offsets[tb]); the accumulation grids are one resident round of waves and
     // the per-lane segment length is derived from the count on the device
     plan.total_entries = tot;
-    plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * 2u * 64u;
+    plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * (uint32_t)(ctx->opt_g1_waves > 0 ? ctx->opt_g1_waves : 2) * 64u;
     plan.lanes_g2 = (uint32_t)ctx->num_cus * 4u * 1u * 64u;
     ws.seg_params.ensure(2 * sizeof(uint32_t));
     hipLaunchKernelGGL(msm_seg_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ws.offsets.as<uint32_t>() + tb, plan.lanes_g1, plan.lanes_g2,
@@ -521,6 +521,28 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *p, size_t n16, ui
 static void zero_fill(hipStream_t st, void *p, size_t bytes, uint32_t *also) {
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4 *>(p), n16, also);
+}
+
+// head/tail partials of the lanes -> buckets (short chains per bucket), then the few buckets that span many lanes
+template <class F>
+static void msm_launch_fixups(zkg16_ctx *ctx, MsmSlot &slot, hipStream_t fs) {
+    AccArgs<F> a;
+    memcpy(&a, slot.acc_args, sizeof a);
+    const size_t psz = sizeof(XYZZ<F>);
+    uint32_t *long_list = slot.long_list.as<uint32_t>() + 1, *long_count = slot.long_list.as<uint32_t>();
+    {
+        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)slot.acc_grid * 64, fs);
+        hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(slot.acc_grid), dim3(64), 0, fs, a, long_list, long_count);
+    }
+    static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
+    if (!lds_attr_set) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_set = true;
+    }
+    {
+        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0, fs);
+        hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, fs, a, long_list, long_count);
+    }
 }
 
 template <class F>
@@ -560,24 +582,11 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
         hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
     }
-    {
-        // fix-ups stay on the main stream: measured faster than moving them behind the reductions on the aux stream
-        hipStream_t fs = ctx->stream;
-        uint32_t *long_list = slot.long_list.as<uint32_t>() + 1, *long_count = slot.long_list.as<uint32_t>();
-        {
-            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)nseg, fs);
-            hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(grid), dim3(64), 0, fs, a, long_list, long_count);
-        }
-        static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
-        if (!lds_attr_set) {
-            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            lds_attr_set = true;
-        }
-        {
-            ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0, fs);
-            hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, fs, a, long_list, long_count);
-        }
-    }
+    static_assert(sizeof(AccArgs<F>) <= sizeof(slot.acc_args), "MsmSlot::acc_args too small");
+    memcpy(slot.acc_args, &a, sizeof a);
+    slot.acc_grid = grid;
+    slot.fixups_pending = ctx->opt_fixup_aux != 0;
+    if (!slot.fixups_pending) msm_launch_fixups<F>(ctx, slot, ctx->stream);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(slot.acc_done, ctx->stream));
     slot.red_buckets = a.buckets;
@@ -602,6 +611,10 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     struct { XYZZ<F> *buckets; } a{reinterpret_cast<XYZZ<F> *>(slot.red_buckets)};
     hipStream_t aux = slot.stream;
     ZK_HIP(hipStreamWaitEvent(aux, slot.acc_done, 0));
+    if (slot.fixups_pending) {      // the next accumulation on the main stream does not depend on them
+        msm_launch_fixups<F>(ctx, slot, aux);
+        slot.fixups_pending = false;
+    }
     const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
     int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : 8;
     while ((size_t)kk > plan.nb) kk >>= 1;
