@@ -139,6 +139,14 @@ ZKG16_API int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[2
                  const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs,
                  const uint64_t proof[48], const uint8_t inf[3], int *ok);
 
+/* prod_i e(P_i, Q_i) == 1 ?  Host-only (no ctx, no GPU).  g1: n x 12 limbs, g2: n x 24 limbs, flag bytes nullable.
+ * flags: ZKG16_PAIRING_PLAIN_FINAL_EXP = final exponentiation as one plain power by (q^12-1)/r (slow cross-check of the
+ * default Frobenius + |z|-chain path).  The building block of zkg16_verify; mirrors ark-ec's `Pairing::multi_pairing`
+ * followed by the `== one` test of verifier.rs. */
+#define ZKG16_PAIRING_PLAIN_FINAL_EXP 1
+ZKG16_API int zkg16_pairing_check(const uint64_t *g1, const uint8_t *g1_inf, const uint64_t *g2, const uint8_t *g2_inf, size_t n,
+                        int flags, int *ok);
+
 /* ---- host-side circuit synthesis (row a2: stays on the host; no ctx, no GPU).  C++ mirrors of the reference's circuits with
  * the same allocation order (variable k here = variable k in arkworks):
  *   MatrixCircuit     src/arkworks/matrix_proof_of_work/constraints.rs:78-128 (+ Poseidon hasher.rs:17-40, hashing_utils.rs:15-877)

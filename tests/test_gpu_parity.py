@@ -373,6 +373,7 @@ def test_setup_prove_verify_with_pairings(dev):
         assert not PP.groth16_verify(vk, bad, pr)
         # the product's own host verifier through the handler mirror agrees
         assert handlers.verify_proof(d["vk"], circ.public_inputs, res["proof"])["valid"] is True
+        assert handlers.verify_proof(res["vk"], circ.public_inputs, res["proof"])["valid"] is True      # key over the wire
         assert handlers.verify_proof(d["vk"], fr_mont_vec(bad), res["proof"])["valid"] is False
 
 

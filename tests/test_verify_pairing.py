@@ -72,3 +72,31 @@ def test_product_verifier_matches_python_pairing():
         tampered[36:] = g1_limbs(case["proof"]["a"])[0]          # C := A
         assert verify(vk, fr_mont_vec(pub), tampered, [0, 0, 0]) is False
         assert dt < 5.0
+
+
+def test_pairing_check_bilinearity_and_both_final_exponentiations():
+    """zkg16_pairing_check (projective multi-Miller loop + Frobenius/|z|-chain final exponentiation) against the pure-Python
+    pairing and against its own plain (q^12-1)/r exponentiation: e(aP, bQ) e(-abP, Q) = 1, wrong products fail, points at
+    infinity contribute 1, and the empty product is 1."""
+    import random
+    from zksnark_finalproject_amd.device import pairing_check
+    rng = random.Random(31)
+    for trial in range(3):
+        a, b, c = (rng.randrange(1, P.R_MOD) for _ in range(3))
+        good = [(P.g1_mul(a), P.g2_mul(b)), (P.ec_neg(P.g1_mul(a * b % P.R_MOD)), P.G2_GEN)]
+        bad = [(P.g1_mul(a), P.g2_mul(b)), (P.ec_neg(P.g1_mul((a * b + 1) % P.R_MOD)), P.G2_GEN)]
+        three = [(P.g1_mul(a), P.g2_mul(b)), (P.g1_mul(c), P.g2_mul(a)), (P.ec_neg(P.g1_mul((a * b + a * c) % P.R_MOD)), P.G2_GEN)]
+        for pairs, expect in ((good, True), (bad, False), (three, True)):
+            g1 = np.array([py_g1(p)[0] for p, _ in pairs], dtype=np.uint64)
+            g2 = np.array([py_g2(q)[0] for _, q in pairs], dtype=np.uint64)
+            assert pairing_check(g1, g2) is expect
+            if trial == 0:
+                assert pairing_check(g1, g2, plain_final_exp=True) is expect
+                assert PP.pairing_product_is_one(pairs) is expect
+    # infinity on either side: that pair drops out
+    g1 = np.array([py_g1(P.g1_mul(5))[0], np.zeros(12, dtype=np.uint64)], dtype=np.uint64)
+    g2 = np.array([np.zeros(24, dtype=np.uint64), py_g2(P.g2_mul(7))[0]], dtype=np.uint64)
+    assert pairing_check(g1, g2, g1_inf=[0, 1], g2_inf=[1, 0]) is True
+    assert pairing_check(np.zeros((0, 12), dtype=np.uint64), np.zeros((0, 24), dtype=np.uint64)) is True
+    # a single non-degenerate pairing is not 1
+    assert pairing_check(np.array([py_g1(P.G1_GEN)[0]]), np.array([py_g2(P.G2_GEN)[0]])) is False

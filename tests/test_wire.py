@@ -47,3 +47,19 @@ def test_hash_encoding():
     for v in (0, 1, P.R_MOD - 1, 0x1234567890abcdef << 100):
         s = wire.encode_hash(fr_mont(v))
         assert unlimbs(wire.decode_hash(s)) == P.fr_to_mont(v % P.R_MOD)
+
+
+def test_verifying_key_roundtrip():
+    """VerifyingKey compressed (ark CanonicalSerialize field order + u64 length prefix): sizes and round trip; parity with
+    arkworks' bytes is unpinned beyond the point encoding itself (the reference holds no vk fixture)."""
+    from zksnark_finalproject_amd import wire
+    rng = random.Random(9)
+    for n in (1, 4):
+        vk = dict(alpha_g1=py_g1(P.g1_mul(P.rand_fr(rng)))[0], beta_g2=py_g2(P.g2_mul(P.rand_fr(rng)))[0],
+                  gamma_g2=py_g2(P.g2_mul(P.rand_fr(rng)))[0], delta_g2=py_g2(P.g2_mul(P.rand_fr(rng)))[0],
+                  gamma_abc_g1=np.array([py_g1(P.g1_mul(P.rand_fr(rng)))[0] for _ in range(n)], dtype=np.uint64))
+        raw = wire.vk_serialize_compressed(vk)
+        assert len(raw) == 48 + 3 * 96 + 8 + 48 * n and raw[336:344] == n.to_bytes(8, "little")
+        back = wire.decode_vk(wire.encode_vk(vk))
+        for k in vk:
+            assert np.array_equal(np.asarray(back[k]).reshape(-1), np.asarray(vk[k]).reshape(-1)), k

@@ -1,11 +1,19 @@
 // Groth16 verification on the host (scope row f-3; the other half of the reference's handlers:
 // `Groth16::<Bls12_381>::verify_with_processed_vk` at /root/reference/src/arkworks/backend/matrix_proof.rs:200-205,
 // fibbonaci_handler.rs:129-140, prime_snark.rs:191-200; upstream ark-groth16 verifier.rs + ark-ec bls12 pairing).
-// Pure host code — verification is ~2 ms in the reference and not on the hot path; this version favours being obviously
-// right over speed: optimal-ate Miller loop with G2 kept on the M-type twist (affine, slopes in Fq2), line values as
-// sparse elements of Fq12 = Fq2[w]/(w^6 - (1+u)), and the final exponentiation as a plain exponentiation by
-// (q^12 - 1)/r.  The loop count |z| is used without the sign correction (e(P,Q)^-1 consistently), which leaves
-// pairing-product equations unchanged.
+// Pure host code (no HIP call): verification is a few milliseconds in the reference and not on the hot path.
+//
+//   * Fq12 = Fq2[w]/(w^6 - xi), xi = 1 + u, kept flat as six Fq2 coefficients (the even ones form Fq6 = Fq2[v]/(v^3 - xi)
+//     with v = w^2, which is what the inversion uses).
+//   * One Miller loop for all pairs (the squaring of f is shared): optimal ate over |z| = 0xd201000000010000, G2 on the
+//     M-type twist in homogeneous projective coordinates (no inversions), line values as sparse elements
+//     c0 + c2 w^2 + c3 w^3 scaled by Fq2 factors the final exponentiation removes.
+//   * Final exponentiation: easy part f^((q^6-1)(q^2+1)) with one inversion and a Frobenius; hard part via
+//     3 (q^4 - q^2 + 1)/r = (z-1)^2 (z+q) (z^2+q^2-1) + 3 (Hayashida-Hayasaka-Teruya), i.e. five exponentiations by |z|.
+//     The result is the cube of the reduced pairing; gcd(3, r) = 1, so "== 1" is unchanged.  The plain exponentiation by
+//     (q^12-1)/r is kept as a cross-check (ZKG16_PAIRING_PLAIN_FINAL_EXP; tests compare the two verdicts).
+//   * The loop count is used without the sign correction for z < 0 (every pairing comes out inverted, consistently),
+//     which leaves pairing-product equations unchanged.
 #include <string.h>
 
 #include <vector>
@@ -19,6 +27,8 @@ namespace {
 
 #include "final_exp.inc"
 
+const uint64_t Z_ABS = 0xd201000000010000ULL;
+
 struct Fq12 { Fq2 c[6]; };
 
 Fq12 fq12_one() {
@@ -30,6 +40,8 @@ Fq12 fq12_one() {
 Fq2 mul_xi(const Fq2 &a) {      // a * (1 + u)
     return Fq2{fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)};
 }
+Fq2 fq2_conj(const Fq2 &a) { return Fq2{a.c0, fp_neg(a.c1)}; }
+Fq2 fq2_scale(const Fq2 &a, const Fq &k) { return Fq2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
 Fq12 fq12_mul(const Fq12 &a, const Fq12 &b) {
     Fq2 t[11];
     for (auto &x : t) x = Fq2::zero();
@@ -63,42 +75,169 @@ Fq12 fq12_pow(const Fq12 &a, const uint64_t *e, int nl) {
     }
     return acc;
 }
-
-// line through twist points T, R (tangent when equal) evaluated at P in G1, scaled by w^3:
-//   y_P w^3 - lambda x_P w^2 + (lambda x_T - y_T);   T <- T + R
-Fq12 line_and_add(G2Affine &T, const G2Affine &R, const G1Affine &P) {
-    Fq2 lam;
-    if (T.x == R.x && T.y == R.y) {
-        const Fq2 x2 = f_sqr(T.x);
-        lam = f_mul(f_add(f_dbl(x2), x2), f_inv(f_dbl(T.y)));
-    } else {
-        lam = f_mul(f_sub(R.y, T.y), f_inv(f_sub(R.x, T.x)));
-    }
-    const Fq2 x3 = f_sub(f_sub(f_sqr(lam), T.x), R.x);
-    const Fq2 y3 = f_sub(f_mul(lam, f_sub(T.x, x3)), T.y);
-    Fq12 l;
-    for (auto &x : l.c) x = Fq2::zero();
-    l.c[0] = f_sub(f_mul(lam, T.x), T.y);
-    l.c[2] = f_neg(Fq2{fp_mul(lam.c0, P.x), fp_mul(lam.c1, P.x)});
-    l.c[3] = Fq2{P.y, Fq::zero()};
-    T = G2Affine{x3, y3};
-    return l;
+// x -> x^(q^6): w -> -w, Fq2 fixed.  On the cyclotomic subgroup (after the easy part) this is the inverse.
+Fq12 fq12_conj(const Fq12 &a) {
+    Fq12 r = a;
+    for (int k = 1; k < 6; k += 2) r.c[k] = f_neg(a.c[k]);
+    return r;
 }
 
-Fq12 miller_loop(const G1Affine &P, const G2Affine &Q) {
-    if (P.is_inf() || Q.is_inf()) return fq12_one();
-    const uint64_t z = 0xd201000000010000ULL;
-    Fq12 f = fq12_one();
-    G2Affine T = Q;
-    for (int i = 62; i >= 0; i--) {          // bit 63 is the leading one
-        const Fq12 l = line_and_add(T, G2Affine(T), P);
-        f = fq12_mul(fq12_mul(f, f), l);
-        if ((z >> i) & 1) {
-            const Fq12 l2 = line_and_add(T, Q, P);
-            f = fq12_mul(f, l2);
+// ---- Frobenius: (sum c_i w^i)^q = sum conj(c_i) gamma_i w^i, gamma_i = xi^(i (q-1)/6)
+struct FrobCoeffs {
+    Fq2 g[6];
+    FrobCoeffs() {
+        const Fq2 xi{Fq::one(), Fq::one()};
+        Fq2 base = Fq2::one();            // xi^((q-1)/6)
+        bool started = false;
+        for (int i = 6 * 64 - 1; i >= 0; i--) {
+            if (started) base = f_sqr(base);
+            if ((FROB_EXP[i / 64] >> (i % 64)) & 1) {
+                base = started ? f_mul(base, xi) : xi;
+                started = true;
+            }
         }
+        g[0] = Fq2::one();
+        for (int i = 1; i < 6; i++) g[i] = f_mul(g[i - 1], base);
+    }
+};
+const FrobCoeffs &frob_coeffs() {
+    static FrobCoeffs f;
+    return f;
+}
+Fq12 fq12_frob(const Fq12 &a, int times) {
+    const FrobCoeffs &f = frob_coeffs();
+    Fq12 r = a;
+    for (int t = 0; t < times; t++)
+        for (int i = 0; i < 6; i++) r.c[i] = f_mul(fq2_conj(r.c[i]), f.g[i]);
+    return r;
+}
+
+// ---- inversion through Fq6 = Fq2[v]/(v^3 - xi): a = g + h w, a^-1 = (g - h w) / (g^2 - v h^2)
+struct Fq6 { Fq2 a0, a1, a2; };
+Fq6 fq6_mul(const Fq6 &x, const Fq6 &y) {
+    const Fq2 t0 = f_mul(x.a0, y.a0), t1 = f_mul(x.a1, y.a1), t2 = f_mul(x.a2, y.a2);
+    Fq6 r;
+    r.a0 = f_add(t0, mul_xi(f_add(f_mul(x.a1, y.a2), f_mul(x.a2, y.a1))));
+    r.a1 = f_add(f_add(f_mul(x.a0, y.a1), f_mul(x.a1, y.a0)), mul_xi(t2));
+    r.a2 = f_add(f_add(f_mul(x.a0, y.a2), f_mul(x.a2, y.a0)), t1);
+    return r;
+}
+Fq6 fq6_sub(const Fq6 &x, const Fq6 &y) { return Fq6{f_sub(x.a0, y.a0), f_sub(x.a1, y.a1), f_sub(x.a2, y.a2)}; }
+Fq6 fq6_mul_v(const Fq6 &x) { return Fq6{mul_xi(x.a2), x.a0, x.a1}; }
+Fq6 fq6_inv(const Fq6 &x) {
+    const Fq2 t0 = f_sub(f_sqr(x.a0), mul_xi(f_mul(x.a1, x.a2)));
+    const Fq2 t1 = f_sub(mul_xi(f_sqr(x.a2)), f_mul(x.a0, x.a1));
+    const Fq2 t2 = f_sub(f_sqr(x.a1), f_mul(x.a0, x.a2));
+    const Fq2 d = f_add(f_mul(x.a0, t0), mul_xi(f_add(f_mul(x.a2, t1), f_mul(x.a1, t2))));
+    const Fq2 di = f_inv(d);
+    return Fq6{f_mul(t0, di), f_mul(t1, di), f_mul(t2, di)};
+}
+Fq12 fq12_inv(const Fq12 &a) {
+    const Fq6 g{a.c[0], a.c[2], a.c[4]}, h{a.c[1], a.c[3], a.c[5]};
+    const Fq6 d = fq6_inv(fq6_sub(fq6_mul(g, g), fq6_mul_v(fq6_mul(h, h))));
+    const Fq6 rg = fq6_mul(g, d), rh = fq6_mul(h, d);
+    Fq12 r;
+    r.c[0] = rg.a0; r.c[2] = rg.a1; r.c[4] = rg.a2;
+    r.c[1] = f_neg(rh.a0); r.c[3] = f_neg(rh.a1); r.c[5] = f_neg(rh.a2);
+    return r;
+}
+
+// a^z for a in the cyclotomic subgroup, z = -|z|
+Fq12 pow_z(const Fq12 &a) {
+    Fq12 acc = a;
+    for (int i = 62; i >= 0; i--) {
+        acc = fq12_mul(acc, acc);
+        if ((Z_ABS >> i) & 1) acc = fq12_mul(acc, a);
+    }
+    return fq12_conj(acc);
+}
+// f^(3 (q^12 - 1)/r)
+Fq12 final_exp_fast(const Fq12 &f) {
+    const Fq12 f1 = fq12_mul(fq12_conj(f), fq12_inv(f));       // f^(q^6 - 1)
+    const Fq12 g = fq12_mul(fq12_frob(f1, 2), f1);              // ^(q^2 + 1): now unitary, inverse = conjugate
+    const Fq12 t0 = fq12_mul(pow_z(g), fq12_conj(g));           // g^(z - 1)
+    const Fq12 t1 = fq12_mul(pow_z(t0), fq12_conj(t0));         // g^((z - 1)^2)
+    const Fq12 t2 = fq12_mul(pow_z(t1), fq12_frob(t1, 1));      // ^(z + q)
+    const Fq12 t3 = fq12_mul(fq12_mul(pow_z(pow_z(t2)), fq12_frob(t2, 2)), fq12_conj(t2));      // ^(z^2 + q^2 - 1)
+    return fq12_mul(t3, fq12_mul(fq12_mul(g, g), g));           // * g^3
+}
+
+// ---- Miller loop, all pairs together
+struct G2Proj { Fq2 x, y, z; };
+struct MillerPair {
+    G1Affine p;
+    G2Affine q;
+    G2Proj t;
+};
+const Fq2 &twist_b3() {      // 3 b' = 3 * 4 (1 + u)
+    static const Fq2 v = [] {
+        Fq c = Fq::zero();
+        c.l[0] = 12;
+        const Fq m = fp_to_mont(c);
+        return Fq2{m, m};
+    }();
+    return v;
+}
+Fq12 line_value(const Fq2 &c0, const Fq2 &c2, const Fq2 &c3) {
+    Fq12 l;
+    for (auto &x : l.c) x = Fq2::zero();
+    l.c[0] = c0; l.c[2] = c2; l.c[3] = c3;
+    return l;
+}
+// tangent at T, evaluated at P, scaled by 2 Y Z^2 / Z: (Y^2 - 3b'Z^2) - 3X^2 x_P w^2 + 2YZ y_P w^3;  T <- 2T
+Fq12 dbl_step(MillerPair &m) {
+    const Fq2 &X = m.t.x, &Y = m.t.y, &Z = m.t.z;
+    const Fq2 B = f_sqr(Y), C = f_sqr(Z), J = f_sqr(X);
+    const Fq2 E = f_mul(twist_b3(), C);
+    const Fq2 F = f_add(f_dbl(E), E);
+    const Fq2 H = f_dbl(f_mul(Y, Z));
+    const Fq2 XY = f_mul(X, Y);
+    const Fq12 l = line_value(f_sub(B, E), f_neg(fq2_scale(f_add(f_dbl(J), J), m.p.x)), fq2_scale(H, m.p.y));
+    // (X3, Y3, Z3) = (XY/2 (B - F), ((B + F)/2)^2 - 3E^2, B H); scaled by 4 to stay clear of halving:
+    //   X3' = 2 XY (B - F), Y3' = (B + F)^2 - 12 E^2, Z3' = 4 B H
+    const Fq2 E2 = f_sqr(E);
+    G2Proj r;
+    r.x = f_mul(f_dbl(XY), f_sub(B, F));
+    Fq2 e12 = f_add(f_dbl(E2), E2);      // 3 E^2
+    e12 = f_dbl(f_dbl(e12));             // 12 E^2
+    r.y = f_sub(f_sqr(f_add(B, F)), e12);
+    r.z = f_dbl(f_dbl(f_mul(B, H)));
+    m.t = r;
+    return l;
+}
+// chord through T and Q (affine), scaled by lambda: (theta x_Q - lambda y_Q) - theta x_P w^2 + lambda y_P w^3;  T <- T + Q
+Fq12 add_step(MillerPair &m) {
+    const Fq2 &X = m.t.x, &Y = m.t.y, &Z = m.t.z;
+    const Fq2 theta = f_sub(Y, f_mul(m.q.y, Z));
+    const Fq2 lambda = f_sub(X, f_mul(m.q.x, Z));
+    const Fq2 C = f_sqr(theta), D = f_sqr(lambda);
+    const Fq2 E = f_mul(lambda, D), F = f_mul(Z, C), G = f_mul(X, D);
+    const Fq2 H = f_sub(f_add(E, F), f_dbl(G));
+    const Fq12 l = line_value(f_sub(f_mul(theta, m.q.x), f_mul(lambda, m.q.y)), f_neg(fq2_scale(theta, m.p.x)), fq2_scale(lambda, m.p.y));
+    G2Proj r;
+    r.x = f_mul(lambda, H);
+    r.y = f_sub(f_mul(theta, f_sub(G, H)), f_mul(E, Y));
+    r.z = f_mul(Z, E);
+    m.t = r;
+    return l;
+}
+Fq12 multi_miller_loop(std::vector<MillerPair> &pairs) {
+    Fq12 f = fq12_one();
+    for (auto &m : pairs) m.t = G2Proj{m.q.x, m.q.y, Fq2::one()};
+    for (int i = 62; i >= 0; i--) {          // bit 63 is the leading one
+        f = fq12_mul(f, f);
+        for (auto &m : pairs) f = fq12_mul(f, dbl_step(m));
+        if ((Z_ABS >> i) & 1)
+            for (auto &m : pairs) f = fq12_mul(f, add_step(m));
     }
     return f;
+}
+bool pairing_product_is_one(std::vector<MillerPair> &pairs, bool plain_final_exp) {
+    std::vector<MillerPair> live;
+    for (const auto &m : pairs)
+        if (!m.p.is_inf() && !m.q.is_inf()) live.push_back(m);      // e(O, Q) = e(P, O) = 1
+    const Fq12 f = multi_miller_loop(live);
+    return fq12_is_one(plain_final_exp ? fq12_pow(f, FINAL_EXP, FINAL_EXP_LIMBS) : final_exp_fast(f));
 }
 
 G1Affine g1_neg(const G1Affine &p) { return p.is_inf() ? p : G1Affine{p.x, fp_neg(p.y)}; }
@@ -114,6 +253,22 @@ A load_pt(const uint64_t *l, int inf) {
 }  // namespace
 
 extern "C" {
+
+// prod_i e(P_i, Q_i) == 1 ?   g1: n x 12 limbs, g2: n x 24 limbs (arkworks layout), flag bytes nullable (= none at infinity)
+int zkg16_pairing_check(const uint64_t *g1, const uint8_t *g1_inf, const uint64_t *g2, const uint8_t *g2_inf, size_t n, int flags, int *ok) {
+    if ((n && (!g1 || !g2)) || !ok) return ZKG16_ERR_BAD_ARG;
+    try {
+        std::vector<MillerPair> pairs(n);
+        for (size_t i = 0; i < n; i++) {
+            pairs[i].p = load_pt<G1Affine>(g1 + 12 * i, g1_inf ? g1_inf[i] : 0);
+            pairs[i].q = load_pt<G2Affine>(g2 + 24 * i, g2_inf ? g2_inf[i] : 0);
+        }
+        *ok = pairing_product_is_one(pairs, (flags & ZKG16_PAIRING_PLAIN_FINAL_EXP) != 0) ? 1 : 0;
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    }
+    return ZKG16_OK;
+}
 
 // e(A, B) == e(alpha, beta) * e(sum_i z_i gamma_abc_i, gamma) * e(C, delta) ?
 // gamma_abc_g1: num_instance points (the first pairs with the constant 1); public_inputs: (num_instance - 1) Montgomery Fr.
@@ -134,11 +289,16 @@ int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const 
     const G1Affine X = xyzz_to_affine(acc);
     const G1Affine A = load_pt<G1Affine>(proof, inf[0]), C = load_pt<G1Affine>(proof + 36, inf[2]);
     const G2Affine B = load_pt<G2Affine>(proof + 12, inf[1]);
-    Fq12 f = miller_loop(A, B);
-    f = fq12_mul(f, miller_loop(g1_neg(load_pt<G1Affine>(alpha_g1, 0)), load_pt<G2Affine>(beta_g2, 0)));
-    f = fq12_mul(f, miller_loop(g1_neg(X), load_pt<G2Affine>(gamma_g2, 0)));
-    f = fq12_mul(f, miller_loop(g1_neg(C), load_pt<G2Affine>(delta_g2, 0)));
-    *ok = fq12_is_one(fq12_pow(f, FINAL_EXP, FINAL_EXP_LIMBS)) ? 1 : 0;
+    try {
+        std::vector<MillerPair> pairs(4);
+        pairs[0].p = A; pairs[0].q = B;
+        pairs[1].p = g1_neg(load_pt<G1Affine>(alpha_g1, 0)); pairs[1].q = load_pt<G2Affine>(beta_g2, 0);
+        pairs[2].p = g1_neg(X); pairs[2].q = load_pt<G2Affine>(gamma_g2, 0);
+        pairs[3].p = g1_neg(C); pairs[3].q = load_pt<G2Affine>(delta_g2, 0);
+        *ok = pairing_product_is_one(pairs, false) ? 1 : 0;
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    }
     return ZKG16_OK;
 }
 

@@ -262,3 +262,19 @@ def _setup_resident(self, r1cs_h, num_instance, trapdoor_mont, g1_gen, g2_gen):
 
 
 Device.setup_resident = _setup_resident
+
+
+def pairing_check(g1_points, g2_points, g1_inf=None, g2_inf=None, plain_final_exp=False):
+    """prod e(P_i, Q_i) == 1 on the host (zkg16_pairing_check).  g1_points: n x 12, g2_points: n x 24 Montgomery limbs."""
+    lib = _lib.load()
+    g1 = _u64(g1_points).reshape(-1, 12)
+    g2 = _u64(g2_points).reshape(-1, 24)
+    assert g1.shape[0] == g2.shape[0]
+    n = g1.shape[0]
+    i1 = np.ascontiguousarray(g1_inf if g1_inf is not None else np.zeros(n), dtype=np.uint8)
+    i2 = np.ascontiguousarray(g2_inf if g2_inf is not None else np.zeros(n), dtype=np.uint8)
+    ok = C.c_int(0)
+    rc = lib.zkg16_pairing_check(g1, i1, g2, i2, n, 1 if plain_final_exp else 0, C.byref(ok))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return bool(ok.value)

@@ -56,7 +56,9 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
                 setup_time=out["setup_time"], proving_time=out["proving_time"],
                 # the reference counts matrix_mul twice (outer cs + circuit: matrix_proof.rs:108,150,160)
                 num_constraints=circ.num_constraints + 2 * size ** 3, num_constraints_circuit=circ.num_constraints,
-                num_variables=circ.num_instance, proof=wire.encode_proof(out["proof"], out["inf"]), _detail=out, _circuit=circ)
+                num_variables=circ.num_instance, proof=wire.encode_proof(out["proof"], out["inf"]),
+                # the reference returns the *prepared* key here (encode_pvk, io.rs:53-60); see wire.vk_serialize_compressed
+                vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
 
 
 def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
@@ -65,14 +67,17 @@ def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
-                fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], _detail=out, _circuit=circ)
+                fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
 
 
 def verify_proof(vk, public_inputs_mont, proof_b64):
     """Mirror of the verify handlers (matrix_proof.rs:183-205, fibbonaci_handler.rs:118-145): decode the base64 compressed
-    proof, check the Groth16 equation with the host verifier (zkg16_verify) -> {valid, verifying_time}."""
+    proof (and key, when given as the base64 string the prove mirrors return), check the Groth16 equation with the host
+    verifier (zkg16_verify) -> {valid, verifying_time}."""
     from .device import verify
     t0 = time.perf_counter()
+    if isinstance(vk, str):
+        vk = wire.decode_vk(vk)
     proof, inf = wire.decode_proof(proof_b64)
     ok = verify(vk, public_inputs_mont, proof, inf)
     return dict(valid=bool(ok), verifying_time=time.perf_counter() - t0)

@@ -141,3 +141,36 @@ def decode_hash(s):
     """base64 -> Fr::from_le_bytes_mod_order (matrix_proof.rs:196-198) -> Montgomery limbs"""
     v = int.from_bytes(base64.standard_b64decode(s), "little") % R
     return _limbs((v << 256) % R, 4)
+
+
+def vk_serialize_compressed(vk):
+    """VerifyingKey -> ark `CanonicalSerialize` compressed bytes: alpha_g1 (48) | beta_g2 (96) | gamma_g2 (96) | delta_g2 (96) |
+    len(gamma_abc_g1) as u64 LE | gamma_abc_g1 (48 each)   (ark-groth16 data_structures.rs field order; Vec = u64 length
+    prefix).  The reference ships the *prepared* key (`encode_pvk`, io.rs:53-60): that additionally holds e(alpha, beta) in
+    arkworks' Fq12 tower and the two G2Prepared line-coefficient vectors, whose bytes depend on upstream-internal formula
+    choices that cannot be pinned offline — not produced here; a prepared key is recomputable from these bytes."""
+    gabc = np.asarray(vk["gamma_abc_g1"], dtype=np.uint64).reshape(-1, 12)
+    out = g1_compress(vk["alpha_g1"], 0) + g2_compress(vk["beta_g2"], 0) + g2_compress(vk["gamma_g2"], 0) + g2_compress(vk["delta_g2"], 0)
+    out += len(gabc).to_bytes(8, "little")
+    for p in gabc:
+        out += g1_compress(p, 0)
+    return out
+
+
+def vk_deserialize_compressed(b):
+    a, _ = g1_decompress(b[:48])
+    beta, _ = g2_decompress(b[48:144])
+    gamma, _ = g2_decompress(b[144:240])
+    delta, _ = g2_decompress(b[240:336])
+    n = int.from_bytes(b[336:344], "little")
+    assert len(b) == 344 + 48 * n
+    gabc = np.array([g1_decompress(b[344 + 48 * i:392 + 48 * i])[0] for i in range(n)], dtype=np.uint64).reshape(n, 12)
+    return dict(alpha_g1=a, beta_g2=beta, gamma_g2=gamma, delta_g2=delta, gamma_abc_g1=gabc)
+
+
+def encode_vk(vk):
+    return base64.standard_b64encode(vk_serialize_compressed(vk)).decode()
+
+
+def decode_vk(s):
+    return vk_deserialize_compressed(base64.standard_b64decode(s))
