@@ -109,6 +109,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
     bool fixups_pending = false;    // fix-ups go with the reduction (aux stream) instead of the accumulation (main stream)
     alignas(16) unsigned char acc_args[128] = {0};
     unsigned acc_grid = 0;
+    int two_level_k = 0;            // K of the work-efficient reduction when it was used for this MSM (0 = classic)
     void *red_buckets = nullptr;
     size_t red_nb = 0;
 };
@@ -139,6 +140,7 @@ struct zkg16_ctx {
     std::map<std::string, zk::KernelStat> kstats;
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
+    int opt_reduce_mode = 0;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level
     int opt_g1_waves = 0;                             // G1 accumulation waves per SIMD in the one resident round (0 = 2)
     int opt_fixup_aux = 0;                            // 1: fix-up kernels on the MSM's reduction stream
     int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
