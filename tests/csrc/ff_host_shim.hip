@@ -3,6 +3,7 @@
 // a machine without a GPU.  Built by tests/test_ff_host.py with `hipcc --offload-host-only`.
 #include "ff.cuh"
 #include "ec.cuh"
+#include "fru.cuh"
 #include <string.h>
 using namespace zk;
 
@@ -90,4 +91,21 @@ int ht_fqu_is_zero_mod_k(int k, int delta) {   // is_zero_mod(k*q + delta) for t
 }
 void ht_g1u_op(int op, const uint32_t *acc, const uint32_t *q, int neg, int reps, uint32_t *oa) { pointu_op<Fq, FqU>(op, acc, q, neg, reps, oa); }
 void ht_g2u_op(int op, const uint32_t *acc, const uint32_t *q, int neg, int reps, uint32_t *oa) { pointu_op<Fq2, Fq2U>(op, acc, q, neg, reps, oa); }
+}
+
+// ---------------------------------------------------------------------------------------------- unsaturated Fr (csrc/fru.cuh)
+extern "C" void ht_fru_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *o) {
+    const Fr sa = ld<Fr>(a), sb = ld<Fr>(b);
+    const FrU x = fru_from_sat(sa), y = fru_from_sat(sb);
+    FrU r;
+    switch (op) {
+        case 0: r = fru_cond_sub<true>(fru_add(x, y)); break;
+        case 1: r = fru_cond_sub<true>(fru_sub_2r(x, y)); break;
+        case 2: r = fru_mul(x, y); break;
+        case 3: r = fru_mul(fru_sub_2r(x, y), y); break;                    // (a - b) b with the un-reduced difference (< 4r)
+        case 4: st(o, fru_mul_to_sat(x, fru_repack(sb))); return;           // store path: U-form times a saturated-form factor
+        case 5: r = fru_mul(fru_repack(sa), fru_mul(fru_repack(sb), fru_c271())); break;     // coset load path: x g
+        default: r = x;
+    }
+    st(o, fru_mul_to_sat(r, fru_one_sat()));
 }

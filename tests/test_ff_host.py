@@ -208,3 +208,22 @@ def test_curve_kat_uform(shim, group):
     assert np.array_equal(pointu_op(shim, group, 0, ax, gen, neg=1, reps=7), py(mul(P.R_MOD - 2))[0])
     assert np.array_equal(pointu_op(shim, group, 2, ax, gen, reps=9), py(mul(5 * 512))[0])
     assert np.array_equal(pointu_op(shim, group, 1, ax, ax, reps=1), py(mul(10))[0])                          # add of equal points -> doubling branch
+
+
+def test_fru_ops_vs_python(shim):
+    """csrc/fru.cuh (the NTT's unsaturated Fr): saturated -> U-form -> op -> saturated equals the plain modular result,
+    including the two conversion-by-multiplication paths the transform uses at load and store."""
+    rng = random.Random(29)
+    r = P.R_MOD
+    vals = [0, 1, 2, r - 1, r - 2, (1 << 254) % r, (1 << 255) % r] + [rng.randrange(r) for _ in range(60)]
+    ops = ((0, lambda x, y: x + y), (1, lambda x, y: x - y), (2, lambda x, y: x * y), (3, lambda x, y: (x - y) * y),
+           (4, lambda x, y: x * y), (5, lambda x, y: x * y))
+    for a in vals[:9]:
+        for b in vals[:9]:
+            for op, f in ops:
+                got = P.fr_from_mont(unlimbs(call_field(shim, "ht_fru_op", op, fr_mont(a), fr_mont(b))))
+                assert got == f(a, b) % r, (op, a, b)
+    for i in range(len(vals) - 1):
+        a, b = vals[i], vals[i + 1]
+        for op, f in ops:
+            assert P.fr_from_mont(unlimbs(call_field(shim, "ht_fru_op", op, fr_mont(a), fr_mont(b)))) == f(a, b) % r, (op, a, b)

@@ -14,6 +14,7 @@
 // staged once per workgroup in LDS.  No MFMA: there is no dense contraction in a modular butterfly.
 // Coset shifts (g = 7) and the 1/N of the inverse ride on the load of pass 1 / the store of pass 2.
 #include "common.hpp"
+#include "fru.cuh"
 
 namespace zk {
 
@@ -182,6 +183,130 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ unsaturated butterflies
+// The same two passes with the arithmetic in FrU (fru.cuh): LDS holds 9 x 29-bit limbs per element; global memory keeps
+// the saturated form, converted by the multiplication each load / store performs anyway (see fru.cuh).  Butterfly values
+// stay below 2r: the sum gets a conditional subtraction of 2r, the difference (a - b + 2r < 4r) goes straight into the
+// twiddle product.
+static constexpr int NTT_THREADS_U = 1024;          // 4 waves per SIMD over one 2048-element tile: one butterfly per thread per stage
+__device__ __forceinline__ FrU lds_ld_u(const uint32_t *s, int stride, int e) {
+    FrU v;
+    const int p = swz(e);
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.l[k] = s[k * stride + p];
+    return v;
+}
+__device__ __forceinline__ void lds_st_u(uint32_t *s, int stride, int e, const FrU &v) {
+    const int p = swz(e);
+#pragma unroll
+    for (int k = 0; k < 9; k++) s[k * stride + p] = v.l[k];
+}
+
+__device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride) {
+    const int tid = threadIdx.x;
+    for (int s = log_m - 1; s >= 0; s--) {
+        const int h = 1 << s;
+        for (int u = tid; u < NTT_TILE / 2; u += NTT_THREADS_U) {
+            const int c = u >> (log_m - 1);
+            const int v = u & ((1 << (log_m - 1)) - 1);
+            const int j = v & (h - 1);
+            const int blk = v >> s;
+            const int i0 = (c << log_m) + (blk << (s + 1)) + j;
+            const int i1 = i0 + h;
+            const FrU a = lds_ld_u(s_data, NTT_TILE, i0);
+            const FrU b = lds_ld_u(s_data, NTT_TILE, i1);
+            const FrU sum = fru_cond_sub<true>(fru_add(a, b));
+            FrU dif = fru_sub_2r(a, b);
+            if (s > 0) dif = fru_mul(dif, lds_ld_u(s_tw, tw_stride, j << (log_m - 1 - s)));
+            else dif = fru_cond_sub<true>(dif);       // the last stage's twiddle is w^0 = 1
+            lds_st_u(s_data, NTT_TILE, i0, sum);
+            lds_st_u(s_data, NTT_TILE, i1, dif);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void stage_twiddles_u(uint32_t *s_tw, int tw_stride, const Fr *w, int log_n, int log_m, int inverse) {
+    const int half = 1 << (log_m > 0 ? log_m - 1 : 0);
+    const unsigned nmask = (1u << log_n) - 1u;
+    for (int e = threadIdx.x; e < half; e += NTT_THREADS_U) {
+        unsigned idx = (unsigned)e << (log_n - log_m);
+        if (inverse) idx = ((1u << log_n) - idx) & nmask;
+        lds_st_u(s_tw, tw_stride, e, fru_from_sat(gld(w + idx)));
+    }
+}
+
+// element load: saturated -> U-form, times the optional per-index multiplier (coset fft)
+__device__ __forceinline__ FrU load_u(const Fr *in, const Fr *pre, size_t gi) {
+    const FrU x = fru_repack(gld(in + gi));
+    if (pre) return fru_mul(x, fru_mul(fru_repack(gld(pre + gi)), fru_c271()));
+    return fru_mul(x, fru_c266());
+}
+
+__global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_data = smem;                         // [9][TILE]
+    uint32_t *s_tw = smem + 9 * NTT_TILE;            // [9][tw_stride]
+    const int tw_stride = 1 << (a.log_n1 - 1);
+    const int log_c = NTT_TILE_LOG - a.log_n1;
+    const int C = 1 << log_c;
+    const unsigned nmask = (1u << a.log_n) - 1u;
+    const size_t n2 = (size_t)1 << a.log_n2;
+    const size_t col0 = (size_t)blockIdx.x * C;
+    const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
+    Fr *out = a.out + (size_t)blockIdx.y * a.batch_stride;
+
+    stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n1, a.inverse);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+        const int c = t & (C - 1), i1 = t >> log_c;
+        const size_t gi = (size_t)i1 * n2 + col0 + c;
+        lds_st_u(s_data, NTT_TILE, (c << a.log_n1) + i1, load_u(in, a.pre, gi));
+    }
+    __syncthreads();
+    lds_dif_u(s_data, s_tw, a.log_n1, tw_stride);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+        const int c = t & (C - 1), k1 = t >> log_c;
+        const FrU v = lds_ld_u(s_data, NTT_TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
+        const size_t i2 = col0 + c;
+        unsigned e = (unsigned)(((i2 * (size_t)k1) << a.tw_shift) & nmask);    // inter-pass twiddle w_M^(i2*k1), w_M = w_N^(2^tw_shift)
+        if (a.inverse) e = ((1u << a.log_n) - e) & nmask;
+        gst(out + (size_t)k1 * n2 + i2, fru_mul_to_sat(v, fru_repack(gld(a.w + e))));      // w[0] is the saturated one
+    }
+}
+
+__global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_data = smem;
+    uint32_t *s_tw = smem + 9 * NTT_TILE;
+    const int tw_stride = a.log_n2 > 0 ? 1 << (a.log_n2 - 1) : 1;
+    const int log_r = NTT_TILE_LOG - a.log_n2;
+    const int R = 1 << log_r;
+    const size_t n1 = (size_t)1 << a.log_n1;
+    const size_t n2 = (size_t)1 << a.log_n2;
+    const size_t row0 = (size_t)blockIdx.x * R;
+    const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
+
+    stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+        const int i2 = t & ((1 << a.log_n2) - 1), r = t >> a.log_n2;
+        FrU v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v.l[k] = 0;
+        if (row0 + r < n1) v = load_u(in, a.pre, (row0 + r) * n2 + i2);
+        lds_st_u(s_data, NTT_TILE, t, v);
+    }
+    __syncthreads();
+    lds_dif_u(s_data, s_tw, a.log_n2, tw_stride);
+    const FrU post_c = a.post_const_on ? fru_repack(a.post_const) : fru_one_sat();
+    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+        const int r = t & (R - 1), k2 = t >> log_r;
+        if (row0 + r >= n1) continue;
+        const FrU v = lds_ld_u(s_data, NTT_TILE, (r << a.log_n2) + bitrev(k2, a.log_n2));
+        const size_t k = (size_t)blockIdx.y + (((row0 + r) + n1 * (size_t)k2) << a.out_stride_log);
+        gst(a.out + k, fru_mul_to_sat(v, a.post ? fru_repack(gld(a.post + k)) : post_c));
+    }
+}
+
 // out[i] = scale * base^i
 __global__ void fr_powers_kernel(Fr *out, Fr base, Fr scale, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,11 +364,16 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
 // In-place from the caller's view: the result ends in `data`; `tmp` (N elements) is scratch.
 void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset) {
     static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // 64 KiB tile + up to 32 KiB of twiddles: above the 64 KiB default dynamic-LDS cap
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_cols), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles: above the 64 KiB default dynamic-LDS cap
+        for (const void *f : {reinterpret_cast<const void *>(ntt_pass_cols), reinterpret_cast<const void *>(ntt_pass_rows),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u), reinterpret_cast<const void *>(ntt_pass_rows_u)})
+            ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
+    const bool uform = ctx->opt_ntt_mode != 0;          // 1 (default): unsaturated butterflies; 0: saturated (the first version)
+    auto *k_cols = uform ? ntt_pass_cols_u : ntt_pass_cols;
+    auto *k_rows = uform ? ntt_pass_rows_u : ntt_pass_rows;
+    const unsigned nthreads = uform ? NTT_THREADS_U : NTT_THREADS;
     if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
     const size_t n = (size_t)1 << log_n;
@@ -256,7 +386,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
     const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
     const int post_const_on = (inverse && !coset) ? 1 : 0;
     a.post_const = t->n_inv;
-    auto lds_bytes = [](int log_m) { return (size_t)8 * 4 * (NTT_TILE + (log_m > 0 ? (1 << (log_m - 1)) : 1)); };
+    auto lds_bytes = [uform](int log_m) { return (size_t)(uform ? 9 : 8) * 4 * (NTT_TILE + (log_m > 0 ? (1 << (log_m - 1)) : 1)); };
 
     if (log_n <= NTT_MAX_SUB_LOG) {
         a.log_n1 = 0;
@@ -267,7 +397,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         a.post = post;
         a.post_const_on = post_const_on;
         ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-        hipLaunchKernelGGL(ntt_pass_rows, dim3(1), dim3(NTT_THREADS), lds_bytes(log_n), ctx->stream, a);
+        hipLaunchKernelGGL(k_rows, dim3(1), dim3(nthreads), lds_bytes(log_n), ctx->stream, a);
     } else {
         // N = N0 * M (N0 = 1 for N <= 2^22): [outer column pass over N0] then the two-pass transform of size M, batched over k0 < N0
         const int log_m = log_n <= 2 * NTT_MAX_SUB_LOG ? log_n : 2 * NTT_MAX_SUB_LOG;
@@ -278,7 +408,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
             p0.log_n1 = log_n0; p0.log_n2 = log_m;
             const unsigned grid = (unsigned)(((size_t)1 << log_m) >> (NTT_TILE_LOG - log_n0));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid), dim3(NTT_THREADS), lds_bytes(log_n0), ctx->stream, p0);
+            hipLaunchKernelGGL(k_cols, dim3(grid), dim3(nthreads), lds_bytes(log_n0), ctx->stream, p0);
         }
         a.log_n2 = log_m / 2;
         a.log_n1 = log_m - a.log_n2;
@@ -291,7 +421,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
             p1.batch_stride = (size_t)1 << log_m;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (NTT_TILE_LOG - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            hipLaunchKernelGGL(ntt_pass_cols, dim3(grid, batches), dim3(NTT_THREADS), lds_bytes(a.log_n1), ctx->stream, p1);
+            hipLaunchKernelGGL(k_cols, dim3(grid, batches), dim3(nthreads), lds_bytes(a.log_n1), ctx->stream, p1);
         }
         {
             NttPassArgs p2 = a;
@@ -302,7 +432,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
             p2.out_stride_log = log_n0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n1) >> (NTT_TILE_LOG - a.log_n2));
             ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-            hipLaunchKernelGGL(ntt_pass_rows, dim3(grid, batches), dim3(NTT_THREADS), lds_bytes(a.log_n2), ctx->stream, p2);
+            hipLaunchKernelGGL(k_rows, dim3(grid, batches), dim3(nthreads), lds_bytes(a.log_n2), ctx->stream, p2);
         }
     }
     ZK_HIP(hipGetLastError());
