@@ -421,6 +421,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_window_bits = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "min_seg")) {
+        if (value < 0 || value > 4096) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_min_seg = (int)value;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "ntt_mode")) {
         if (value < 0 || value > 1) return ZKG16_ERR_BAD_ARG;
         ctx->opt_ntt_mode = (int)value;

@@ -140,6 +140,7 @@ struct zkg16_ctx {
     std::map<std::string, zk::KernelStat> kstats;
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;
+    int opt_min_seg = 0;                              // shortest per-lane run of sorted entries in an accumulation (0 = default)
     int opt_ntt_mode = 1;                             // 1: unsaturated (29-bit limb) butterflies, 0: saturated
     int opt_reduce_mode = 0;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level
     int opt_g1_waves = 0;                             // G1 accumulation waves per SIMD in the one resident round (0 = 2)
