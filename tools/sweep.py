@@ -1,0 +1,36 @@
+"""In-process counterpart of the reference's sweep drivers (bench/matrix.py:10-60: all-ones matrices of size 2^k, prove
+then verify; bench/fibo.py:26-60: Fibonacci rounds 0..186 with a = 0, b = 1), through the handler mirrors instead of
+HTTP.  Records the reference's fields: num_constraints, setup_time, proving_time, verifying_time (seconds).
+    python tools/sweep.py matrix [max_power=6]     |     python tools/sweep.py fib [step=31]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from zksnark_finalproject_amd import Device, handlers
+
+dev = Device(0)
+kind = sys.argv[1] if len(sys.argv) > 1 else "matrix"
+if kind == "matrix":
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    print("size,num_constraints,request_time,setup_time,proving_time,verifying_time,valid")
+    handlers.prove_matrix(dev, 2, np.ones((2, 2), dtype=np.uint64), np.ones((2, 2), dtype=np.uint64))      # warm-up (tables, streams)
+    for k in range(1, top + 1):
+        n = 1 << k
+        ones = np.ones((n, n), dtype=np.uint64)
+        t0 = time.perf_counter()
+        res = handlers.prove_matrix(dev, n, ones, ones, seed=k)
+        t1 = time.perf_counter()
+        v = handlers.verify_proof(res["vk"], res["_circuit"].public_inputs, res["proof"])
+        print("%d,%d,%.4f,%.4f,%.5f,%.5f,%s" % (n, res["num_constraints_circuit"], t1 - t0, res["setup_time"], res["proving_time"],
+                                               v["verifying_time"], v["valid"]), flush=True)
+else:
+    step = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+    print("num_of_rounds,num_constraints,request_time,setup_time,proving_time,verifying_time,valid")
+    handlers.prove_fibonacci(dev, 0, 1, 5)
+    for rounds in range(0, 187, step):
+        t0 = time.perf_counter()
+        res = handlers.prove_fibonacci(dev, 0, 1, rounds)
+        t1 = time.perf_counter()
+        v = handlers.verify_proof(res["vk"], res["_circuit"].public_inputs, res["proof"])
+        print("%d,%d,%.4f,%.4f,%.5f,%.5f,%s" % (rounds, res["num_constraints"], t1 - t0, res["setup_time"], res["proving_time"],
+                                               v["verifying_time"], v["valid"]), flush=True)

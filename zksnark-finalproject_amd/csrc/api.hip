@@ -133,6 +133,77 @@ void upload_one(zkg16_ctx *ctx, typename UOf<A>::T *dst, const A &p) {
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
 
+}  // namespace
+namespace zk {
+// ---- device allocation cache (see common.hpp)
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;     // by (device, size)
+    size_t cached_bytes = 0;
+    static constexpr size_t LIMIT = (size_t)96 << 30, MIN_CACHED = (size_t)1 << 20;
+};
+DevCache &dev_cache() {
+    static DevCache c;
+    return c;
+}
+}  // namespace
+void *dev_acquire(size_t bytes, size_t *got) {
+    DevCache &c = dev_cache();
+    if (bytes >= DevCache::MIN_CACHED) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_blocks.lower_bound(std::make_pair(dev, bytes));
+        if (it != c.free_blocks.end() && it->first.first == dev && it->first.second <= bytes + bytes / 4) {      // at most 25 % larger than asked
+            void *p = it->second;
+            *got = it->first.second;
+            c.cached_bytes -= it->first.second;
+            c.free_blocks.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                      // out of memory with blocks parked in the cache: give them back and retry once
+        (void)hipGetLastError();
+        dev_cache_flush();
+        ZK_HIP(hipMalloc(&p, bytes));
+    }
+    *got = bytes;
+    return p;
+}
+void dev_release(void *p, size_t bytes) noexcept {
+    DevCache &c = dev_cache();
+    if (bytes >= DevCache::MIN_CACHED) {
+        (void)hipDeviceSynchronize();           // what hipFree would have done
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.cached_bytes + bytes <= DevCache::LIMIT) {
+            c.free_blocks.emplace(std::make_pair(dev, bytes), p);
+            c.cached_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+void dev_cache_flush() noexcept {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : c.free_blocks) {
+        (void)hipSetDevice(kv.first.first);
+        (void)hipFree(kv.second);
+    }
+    (void)hipSetDevice(cur);
+    c.free_blocks.clear();
+    c.cached_bytes = 0;
+}
+}  // namespace zk
+namespace {
+
 struct Partials {
     G1XYZZ h, l, a, b1;
     G2XYZZ b2;
@@ -411,6 +482,7 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     (void)hipStreamDestroy(ctx->wm_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    dev_cache_flush();      // a destroyed ctx really returns its memory (other live contexts simply allocate afresh)
 }
 
 int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {

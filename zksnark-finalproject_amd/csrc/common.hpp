@@ -30,7 +30,15 @@ struct HipError {
         if (_e != hipSuccess) throw zk::HipError{_e, #expr, __FILE__, __LINE__}; \
     } while (0)
 
-// RAII device buffer (hipMalloc).  Throws HipError on failure (mapped to a status at the ABI edge).
+// Device allocations go through a small process-wide cache: the reference's request flow builds and drops a proving key
+// (GBs) per request, and hipMalloc / hipFree of buffers that size cost up to seconds on a busy allocator (n = 128: setup
+// measured between 0.47 s and 8 s for identical requests before the cache).  dev_release() synchronises the device first,
+// exactly as hipFree does, so a cached block is never handed out while a kernel may still touch it.
+void *dev_acquire(size_t bytes, size_t *got);      // api.hip; throws HipError
+void dev_release(void *p, size_t bytes) noexcept;
+void dev_cache_flush() noexcept;
+
+// RAII device buffer.  Throws HipError on failure (mapped to a status at the ABI edge).
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -47,11 +55,10 @@ struct DevBuf {
     void alloc(size_t n) {
         release();
         if (n == 0) n = 16;
-        ZK_HIP(hipMalloc(&p, n));
-        bytes = n;
+        p = dev_acquire(n, &bytes);
     }
     void ensure(size_t n) { if (n > bytes) alloc(n); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void release() { if (p) { dev_release(p, bytes); p = nullptr; bytes = 0; } }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 

@@ -47,20 +47,16 @@ __global__ void __launch_bounds__(256) setup_col_offsets_kernel(const uint2 *sor
 // out[k] = sum over the entries of column k of coeff[e] * L[row[e]]   (+ L[nc + k] for k < num_instance when add_inputs)
 // Columns longer than COL_HEAVY entries (the constant-one column of a Poseidon-heavy circuit holds ~10^5) are queued for
 // setup_col_sum_heavy_kernel instead of being walked by one lane.
-constexpr uint32_t COL_HEAVY = 128;
-constexpr uint32_t COL_HEAVY_MAX = 4096;      // queue capacity; overflow falls back to the serial walk
+constexpr uint32_t COL_HEAVY = 1024;          // a lane walks up to this many entries itself (~1 ms)
 __global__ void __launch_bounds__(256) setup_col_sum_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
                                                             const Fr *L, size_t ncols, size_t nc, size_t num_instance, int add_inputs, Fr *out,
-                                                            uint32_t *heavy /* [0] = count, then column ids */) {
+                                                            uint32_t *heavy /* [0] = count, then column ids: room for every column */) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncols) return;
     const uint32_t lo = offsets[k], hi = offsets[k + 1];
     if (hi - lo > COL_HEAVY) {
-        const uint32_t slot = atomicAdd(heavy, 1u);
-        if (slot < COL_HEAVY_MAX) {
-            heavy[1 + slot] = (uint32_t)k;
-            return;
-        }
+        heavy[1 + atomicAdd(heavy, 1u)] = (uint32_t)k;
+        return;
     }
     Fr acc = Fr::zero();
     for (uint32_t p = lo; p < hi; p++) {
@@ -75,7 +71,7 @@ __global__ void __launch_bounds__(256) setup_col_sum_heavy_kernel(const uint2 *s
                                                                   const Fr *L, size_t nc, size_t num_instance, int add_inputs, Fr *out,
                                                                   const uint32_t *heavy) {
     __shared__ uint32_t part[8][256];
-    const uint32_t cnt = heavy[0] < COL_HEAVY_MAX ? heavy[0] : COL_HEAVY_MAX;
+    const uint32_t cnt = heavy[0];
     for (uint32_t q = blockIdx.x; q < cnt; q += gridDim.x) {
         const uint32_t k = heavy[1 + q];
         const uint32_t lo = offsets[k], hi = offsets[k + 1];
@@ -164,7 +160,7 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
 
     // u, v, w: per-matrix column sums
     DevBuf uvw[3];
-    DevBuf keys, sorted, rowid, coloff, sort_temp, heavy((1 + COL_HEAVY_MAX) * sizeof(uint32_t));
+    DevBuf keys, sorted, rowid, coloff, sort_temp, heavy((1 + nv) * sizeof(uint32_t));
     unsigned key_bits = 1;
     while (((size_t)1 << key_bits) <= nv) key_bits++;
     for (int k = 0; k < 3; k++) {
