@@ -472,6 +472,7 @@ void zkg16_destroy(zkg16_ctx *ctx) {
         sl.seg_tail.release();
         sl.seg_meta.release();
         sl.long_list.release();
+        sl.long_sums.release();
         sl.red_a.release(); sl.red_b.release(); sl.red_c.release();
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
     }

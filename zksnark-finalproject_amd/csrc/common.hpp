@@ -105,7 +105,7 @@ struct R1csDev {
 struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
-    DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list, red_a, red_b, red_c;
+    DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list, long_sums, red_a, red_b, red_c;
     hipStream_t stream = nullptr;   // this MSM's reduction runs here
     void *wsums_host = nullptr;   // pinned
     size_t host_bytes = 0;

@@ -198,11 +198,22 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
 
 // One lane per segment whose last bucket spills over: add the head partials of the following segments.
 // Chains longer than FIXUP_SHORT segments (a bucket holding thousands of terms: the value-1 scalars of the
-// reference's witnesses) are queued for msm_fixup_long, which gives each a whole workgroup.
+// reference's witnesses; every bit-valued witness of the Fermat circuit) are cut into items of FIXUP_ITEM
+// head partials and queued for msm_fixup_long (one workgroup per item); a chain of several items gets its item sums
+// folded by msm_fixup_fold.  Without the cut a bucket spanning the whole grid (131,072 partials when every scalar is 1)
+// kept one workgroup busy for 11 ms.
 static constexpr int FIXUP_SHORT = 4;
+static constexpr uint32_t FIXUP_ITEM = 1024;
+// queue layout in MsmSlot::long_list: [0] item count, [1] chain count, then uint2 items[cap_items] = (segment, item index
+// within its chain), then uint4 chains[] = (segment, first item, number of items, -)
+struct FixQueue {
+    uint32_t *counts;
+    uint2 *items;
+    uint4 *chains;
+};
 
 template <class F>
-__global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *long_list, uint32_t *long_count) {
+__global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, FixQueue q) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t seg_len = *a.seg_len_ptr;
     if (t * seg_len >= (size_t)*a.total_ptr) return;
@@ -210,7 +221,10 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *l
     if (g < 0) return;
     const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / seg_len;   // segment holding the bucket's last term
     if (last_seg - t > FIXUP_SHORT) {
-        long_list[atomicAdd(long_count, 1u)] = (uint32_t)t;
+        const uint32_t n_items = (uint32_t)((last_seg - t + FIXUP_ITEM - 1) / FIXUP_ITEM);
+        const uint32_t base = atomicAdd(q.counts, n_items);
+        for (uint32_t j = 0; j < n_items; j++) q.items[base + j] = make_uint2((uint32_t)t, j);
+        if (n_items > 1) q.chains[atomicAdd(q.counts + 1, 1u)] = make_uint4((uint32_t)t, base, n_items, 0u);
         return;
     }
     XYZZ<F> sum = ldv(a.seg_tail + t);
@@ -221,35 +235,66 @@ __global__ void __launch_bounds__(64) msm_fixup_kernel(AccArgs<F> a, uint32_t *l
     stv(a.buckets + g, sum);
 }
 
-// One 256-lane workgroup per long chain (grid-stride over the queue): lanes stride over the chain's head partials,
-// then a log-depth LDS tree folds the 256 lane sums.
+// workgroup-wide sum of one XYZZ per lane (256 lanes) through LDS; result in sh[0]
 template <class F>
-__global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, const uint32_t *long_list, const uint32_t *long_count) {
+__device__ __forceinline__ void block_fold(XYZZ<F> *sh, const XYZZ<F> &mine) {
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            XYZZ<F> x = sh[threadIdx.x];
+            const XYZZ<F> y = sh[threadIdx.x + d];
+            xyzz_add(x, y);
+            sh[threadIdx.x] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// One 256-lane workgroup per item (grid-stride over the queue): lanes stride over the item's head partials (the first
+// item of a chain also takes the tail partial), then a log-depth LDS tree folds the 256 lane sums.  A single-item chain
+// goes straight to its bucket, the others to item_sums[].
+template <class F>
+__global__ void __launch_bounds__(256) msm_fixup_long_kernel(AccArgs<F> a, FixQueue q, XYZZ<F> *item_sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fix_smem[];
     XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(fix_smem);
-    const uint32_t n_long = *long_count;
-    for (uint32_t item = blockIdx.x; item < n_long; item += gridDim.x) {
-        const size_t t = long_list[item];
+    const uint32_t n_items = q.counts[0];
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const size_t t = q.items[item].x, j = q.items[item].y;
         const int32_t g = a.seg_meta[2 * t + 1];
         const size_t last_seg = ((size_t)a.offsets[g + 1] - 1) / (size_t)*a.seg_len_ptr;
+        const size_t lo = t + 1 + j * FIXUP_ITEM;
+        const size_t hi = lo + FIXUP_ITEM - 1 < last_seg ? lo + FIXUP_ITEM - 1 : last_seg;
         XYZZ<F> sum = XYZZ<F>::inf();
-        if (threadIdx.x == 0) sum = ldv(a.seg_tail + t);
-        for (size_t u = t + 1 + threadIdx.x; u <= last_seg; u += blockDim.x) {
+        if (threadIdx.x == 0 && j == 0) sum = ldv(a.seg_tail + t);
+        for (size_t u = lo + threadIdx.x; u <= hi; u += blockDim.x) {
             const XYZZ<F> h = ldv(a.seg_head + u);
             xyzz_add(sum, h);
         }
-        sh[threadIdx.x] = sum;
-        __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
-            if ((int)threadIdx.x < d) {
-                XYZZ<F> x = sh[threadIdx.x];
-                const XYZZ<F> y = sh[threadIdx.x + d];
-                xyzz_add(x, y);
-                sh[threadIdx.x] = x;
-            }
-            __syncthreads();
+        block_fold(sh, sum);
+        if (threadIdx.x == 0) {
+            if (last_seg - t <= FIXUP_ITEM) stv(a.buckets + g, sh[0]);
+            else stv(item_sums + item, sh[0]);
         }
-        if (threadIdx.x == 0) stv(a.buckets + g, sh[0]);
+        __syncthreads();
+    }
+}
+
+// chains of several items: fold the item sums into the bucket
+template <class F>
+__global__ void __launch_bounds__(256) msm_fixup_fold_kernel(AccArgs<F> a, FixQueue q, const XYZZ<F> *item_sums) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fix_smem[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(fix_smem);
+    const uint32_t n_chains = q.counts[1];
+    for (uint32_t c = blockIdx.x; c < n_chains; c += gridDim.x) {
+        const uint4 ch = q.chains[c];
+        XYZZ<F> sum = XYZZ<F>::inf();
+        for (uint32_t i = threadIdx.x; i < ch.z; i += blockDim.x) {
+            const XYZZ<F> h = ldv(item_sums + ch.y + i);
+            xyzz_add(sum, h);
+        }
+        block_fold(sh, sum);
+        if (threadIdx.x == 0) stv(a.buckets + a.seg_meta[2 * (size_t)ch.x + 1], sh[0]);
         __syncthreads();
     }
 }
@@ -544,7 +589,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 __global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *p, size_t n16, uint32_t *also) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
-    if (i == 0 && also) *also = 0;
+    if (i == 0 && also) also[0] = also[1] = 0;
 }
 static void zero_fill(hipStream_t st, void *p, size_t bytes, uint32_t *also) {
     const size_t n16 = bytes / 16;
@@ -553,23 +598,35 @@ static void zero_fill(hipStream_t st, void *p, size_t bytes, uint32_t *also) {
 
 // head/tail partials of the lanes -> buckets (short chains per bucket), then the few buckets that span many lanes
 template <class F>
+static FixQueue fix_queue(MsmSlot &slot, size_t nseg) {
+    const size_t cap_items = nseg + 16, cap_chains = nseg / FIXUP_ITEM + 16;
+    slot.long_list.ensure(16 + cap_items * sizeof(uint2) + cap_chains * sizeof(uint4));
+    slot.long_sums.ensure(cap_items * sizeof(XYZZ<F>));
+    unsigned char *p = slot.long_list.as<unsigned char>();
+    return FixQueue{reinterpret_cast<uint32_t *>(p), reinterpret_cast<uint2 *>(p + 16), reinterpret_cast<uint4 *>(p + 16 + cap_items * sizeof(uint2))};
+}
+// head/tail partials of the lanes -> buckets (short chains per bucket), then the few buckets that span many lanes
+template <class F>
 static void msm_launch_fixups(zkg16_ctx *ctx, MsmSlot &slot, hipStream_t fs) {
     AccArgs<F> a;
     memcpy(&a, slot.acc_args, sizeof a);
     const size_t psz = sizeof(XYZZ<F>);
-    uint32_t *long_list = slot.long_list.as<uint32_t>() + 1, *long_count = slot.long_list.as<uint32_t>();
+    const FixQueue q = fix_queue<F>(slot, (size_t)slot.acc_grid * 64);
+    XYZZ<F> *sums = slot.long_sums.as<XYZZ<F>>();
     {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)slot.acc_grid * 64, fs);
-        hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(slot.acc_grid), dim3(64), 0, fs, a, long_list, long_count);
+        hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(slot.acc_grid), dim3(64), 0, fs, a, q);
     }
     static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
     if (!lds_attr_set) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_fold_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_long_g2" : "msm_fixup_long_g1", 0.0, fs);
-        hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, fs, a, long_list, long_count);
+        hipLaunchKernelGGL(msm_fixup_long_kernel<F>, dim3(512), dim3(256), 256 * psz, fs, a, q, sums);
+        hipLaunchKernelGGL(msm_fixup_fold_kernel<F>, dim3(64), dim3(256), 256 * psz, fs, a, q, sums);
     }
 }
 
@@ -592,8 +649,8 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     slot.seg_head.ensure(nseg * psz);
     slot.seg_tail.ensure(nseg * psz);
     slot.seg_meta.ensure(nseg * 2 * sizeof(int32_t));
-    slot.long_list.ensure((nseg + 1) * sizeof(uint32_t));
-    zero_fill(ctx->stream, slot.buckets.p, tb * psz, slot.long_list.as<uint32_t>());      // + the long-fix-up counter
+    const FixQueue fq = fix_queue<F>(slot, (nseg + 63) / 64 * 64);
+    zero_fill(ctx->stream, slot.buckets.p, tb * psz, fq.counts);      // + the two fix-up queue counters
     AccArgs<F> a;
     a.bases = bases;
     a.entries = ws.entries.as<uint2>();
