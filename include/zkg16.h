@@ -191,8 +191,9 @@ ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t 
  * [0] spmv, [1] ntt+pointwise, [2] msm digits+sort, [3] msm H, [4] msm L, [5] msm A, [6] msm B1, [7] msm B2,
  * [8] host tail, [9] total wall.  Returns the number of entries written. */
 ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
-/* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0/1.  stats are
- * accumulated per kernel name since the last reset. */
+/* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0 off, 1 every kernel family, 2 only the
+ * bucket-accumulation launches (five event pairs per proof instead of ~60).  stats are accumulated per kernel name since
+ * the last reset. */
 ZKG16_API int zkg16_kernel_timing(zkg16_ctx *ctx, int enable);
 ZKG16_API int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms,
                        double *units /* kernel-specific work units, e.g. bucket additions */);

@@ -14,6 +14,7 @@ namespace zk {
 ScopedKernelTimer::ScopedKernelTimer(zkg16_ctx *c, const char *n, double u, hipStream_t st)
     : ctx(c), name(n), units(u), stream(st ? st : c->stream) {
     if (!ctx->kernel_timing) return;
+    if (ctx->kernel_timing_accumulate_only && strncmp(n, "msm_accumulate", 14) != 0) return;
     ZK_HIP(hipEventCreate(&e0));
     ZK_HIP(hipEventCreate(&e1));
     ZK_HIP(hipEventRecord(e0, stream));
@@ -927,6 +928,7 @@ int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {
     if (!ctx) return ZKG16_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->kernel_timing = enable != 0;
+    ctx->kernel_timing_accumulate_only = enable == 2;
     return ZKG16_OK;
 }
 

@@ -144,6 +144,7 @@ struct zkg16_ctx {
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
     float timings[16] = {0};
     bool kernel_timing = false;
+    bool kernel_timing_accumulate_only = false;       // zkg16_kernel_timing(ctx, 2): only the bucket-accumulation launches
     std::map<std::string, zk::KernelStat> kstats;
     std::vector<zk::PendingEvent> pending_events;
     int opt_window_bits = 0;

@@ -184,6 +184,7 @@ class Device:
         return {names[i]: float(buf[i]) for i in range(n)}
 
     def kernel_timing(self, enable=True):
+        """0/False off, 1/True all kernel families, 2 only the bucket accumulations"""
         self._check(self.lib.zkg16_kernel_timing(self.ctx, int(enable)))
 
     def kernel_stats(self, name):
