@@ -208,6 +208,10 @@ namespace {
 struct Partials {
     G1XYZZ h, l, a, b1;
     G2XYZZ b2;
+    // un-sharded proofs: s*(a + alpha) and r*(b1 + beta) are formed on the host as soon as A and B1 are collected, while the
+    // device still works on the remaining MSMs (they are ~0.35 ms of the 0.4 ms host tail)
+    bool have_early = false;
+    G1XYZZ s_a, r_b1;
 };
 
 double now_ms() {
@@ -305,8 +309,24 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
     out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
     out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
-    out.a = msm_g1_collect(ctx, ctx->slots[3]); lap(5);
-    out.b1 = msm_g1_collect(ctx, ctx->slots[4]); lap(6);
+    out.a = msm_g1_collect(ctx, ctx->slots[3]);
+    const bool early = pk.shard_count == 1;
+    if (early) {
+        G1XYZZ A = out.a;
+        xyzz_madd(A, pk.alpha_g1, false);
+        const Fr sc = fp_from_mont(s);
+        out.s_a = xyzz_mul(A, sc.l);
+    }
+    lap(5);
+    out.b1 = msm_g1_collect(ctx, ctx->slots[4]);
+    if (early) {
+        G1XYZZ B1 = out.b1;
+        xyzz_madd(B1, pk.beta_g1, false);
+        const Fr rc_ = fp_from_mont(r);
+        out.r_b1 = xyzz_mul(B1, rc_.l);
+        out.have_early = true;
+    }
+    lap(6);
     out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
     float ms;
     // [1] witness map, [2] digits+sort of both vectors (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2
@@ -332,9 +352,15 @@ void prove_tail_pts(const G1Affine &alpha_g1, const G1Affine &beta_g1, const G2A
     xyzz_madd(B1, beta_g1, false);
     G2XYZZ B2 = p.b2;
     xyzz_madd(B2, beta_g2, false);
-    const Fr rc = fp_from_mont(r), sc = fp_from_mont(s);
-    G1XYZZ C = xyzz_mul(A, sc.l);
-    G1XYZZ rB = xyzz_mul(B1, rc.l);
+    G1XYZZ C, rB;
+    if (p.have_early) {
+        C = p.s_a;
+        rB = p.r_b1;
+    } else {
+        const Fr rc = fp_from_mont(r), sc = fp_from_mont(s);
+        C = xyzz_mul(A, sc.l);
+        rB = xyzz_mul(B1, rc.l);
+    }
     xyzz_add(C, rB);
     xyzz_add(C, p.l);
     xyzz_add(C, p.h);
