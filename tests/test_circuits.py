@@ -120,3 +120,22 @@ def test_poseidon_template_replay_equals_generic_synthesis(n, monkeypatch):
         for x, y in zip(fast.r1cs[m], plain.r1cs[m]):
             assert np.array_equal(x, y), m
     assert np.array_equal(fast.z, plain.z)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7])
+def test_segmented_threaded_build_equals_in_order_build(n, monkeypatch):
+    """zkg16_circuit_matrix builds the hash_a / hash_b gadgets on their own threads into segments placed by a predicted
+    witness offset (csrc/circuits.hip); in-order building (ZKG16_SYNTH_THREADS=0) must give the same CSR arrays and assignment.
+    n = 1 exercises the path where the prediction does not apply."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    rng = np.random.default_rng(100 + n)
+    a = rng.integers(0, 1 << 30, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 30, size=(n, n), dtype=np.uint64)
+    fast = matrix_circuit(a, b)
+    monkeypatch.setenv("ZKG16_SYNTH_THREADS", "0")
+    plain = matrix_circuit(a, b)
+    assert fast.num_constraints == plain.num_constraints and fast.num_vars == plain.num_vars
+    for m in ("a", "b", "c"):
+        for x, y in zip(fast.r1cs[m], plain.r1cs[m]):
+            assert np.array_equal(x, y), m
+    assert np.array_equal(fast.z, plain.z)

@@ -19,6 +19,7 @@
 #include <memory>
 #include <new>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkg16.h"
@@ -70,6 +71,11 @@ struct Circuit {
         void push(const std::vector<Term> &row) { t.insert(t.end(), row.begin(), row.end()); ptr.push_back(t.size()); }
     } rows[3];
 
+    // A circuit may be built as several segments (zkg16_circuit): a segment's own witnesses are numbered from wit_base in
+    // the whole circuit's numbering; variables of earlier segments are referenced by id only (their values travel in Lc::val).
+    size_t wit_base = 0;
+    size_t next_wit() const { return wit_base + witness.size(); }
+
     Circuit() { instance.push_back(Fr::one()); }
 
     Lc constant(const Fr &c) const {
@@ -90,7 +96,7 @@ struct Circuit {
     Lc new_witness(const Fr &v) {
         witness.push_back(v);
         Lc r;
-        if (g_terms) r.t.push_back(Term{WIT | (VarId)(witness.size() - 1), Fr::one()});
+        if (g_terms) r.t.push_back(Term{WIT | (VarId)(next_wit() - 1), Fr::one()});
         r.val = v;
         r.is_const = false;
         return r;
@@ -195,7 +201,8 @@ struct Circuit {
         }
         return res;
     }
-    bool satisfied() const {
+    // rows of this segment under the whole circuit's assignment
+    bool satisfied(const std::vector<Fr> &instance, const std::vector<Fr> &witness) const {
         const size_t ni = instance.size();
         auto eval = [&](const Rows &m, size_t i) {
             Fr acc = Fr::zero();
@@ -326,7 +333,7 @@ void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
     for (const PermTemplate &t : tpls.list)
         if (t.slot0_is_one == one0 && t.shape == shape && t.coeff.size() == coeff.size() &&
             memcmp(t.coeff.data(), coeff.data(), coeff.size() * sizeof(Fr)) == 0) { hit = &t; break; }
-    const size_t w0 = cs.witness.size();
+    const size_t w0 = cs.next_wit();
     if (!hit) {
         size_t r0[3], k0[3];
         for (int m = 0; m < 3; m++) { r0[m] = cs.rows[m].size(); k0[m] = cs.rows[m].t.size(); }
@@ -334,7 +341,7 @@ void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
         PermTemplate t;
         t.shape = shape; t.coeff = coeff; t.slot0_is_one = one0;
         t.n_slots = (uint32_t)ids.size();
-        t.n_new = (uint32_t)(cs.witness.size() - w0);
+        t.n_new = (uint32_t)(cs.next_wit() - w0);
         bool ok = true;
         auto to_tpl = [&](VarId v) -> VarId {
             if ((v & WIT) && (v & ~WIT) >= w0) return t.n_slots + (VarId)((v & ~WIT) - w0);
@@ -361,7 +368,7 @@ void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
     g_terms = false;
     permute_gadget_generic(cs, st);
     g_terms = true;
-    if (cs.witness.size() - w0 != hit->n_new) throw std::logic_error("poseidon template: witness count mismatch");
+    if (cs.next_wit() - w0 != hit->n_new) throw std::logic_error("poseidon template: witness count mismatch");
     auto from_tpl = [&](VarId v) -> VarId { return v < hit->n_slots ? ids[v] : (WIT | (VarId)(w0 + (v - hit->n_slots))); };
     for (int m = 0; m < 3; m++) {
         Circuit::Rows &R = cs.rows[m];
@@ -393,9 +400,34 @@ Lc poseidon_hash_gadget(Circuit &cs, const std::vector<Lc> &elems) {
 }  // namespace
 
 struct zkg16_circuit {
-    Circuit cs;
-    std::vector<Fr> public_inputs;     // instance[1..]
+    // segments in row order; segs[0] holds the instance variables.  Witness values: each segment's own, at its wit_base.
+    std::vector<std::unique_ptr<Circuit>> segs;
+    Circuit &head() { return *segs[0]; }
+    const Circuit &head() const { return *segs[0]; }
+    Circuit &add_segment(size_t wit_base) {
+        segs.emplace_back(new Circuit());
+        segs.back()->wit_base = wit_base;
+        return *segs.back();
+    }
+    size_t num_witness() const {
+        size_t n = 0;
+        for (const auto &sg : segs) n += sg->witness.size();
+        return n;
+    }
+    std::vector<Fr> flat_witness() const {
+        std::vector<Fr> w(num_witness());
+        for (const auto &sg : segs)
+            if (!sg->witness.empty()) memcpy(w.data() + sg->wit_base, sg->witness.data(), sg->witness.size() * sizeof(Fr));
+        return w;
+    }
 };
+
+namespace {
+// witnesses one PoseidonSpongeVar hash of `count` (>= 2) variable elements allocates: every permutation 53 S-boxes x 5
+// products, minus the capacity element's S-box of the first permutation (a constant).  Used only to place the segments of
+// the matrix circuit before they are built concurrently; checked against what the builders actually allocated.
+size_t poseidon_hash_witnesses(size_t count) { return (count + POSEIDON_RATE - 1) / POSEIDON_RATE * 265 - 5; }
+}  // namespace
 
 extern "C" {
 
@@ -405,7 +437,7 @@ int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit 
     if (!out) return ZKG16_ERR_BAD_ARG;
     auto c = new (std::nothrow) zkg16_circuit();
     if (!c) return ZKG16_ERR_OOM;
-    Circuit &cs = c->cs;
+    Circuit &cs = c->add_segment(0);
     const Fr fa = fr_from_u64(a), fb = fr_from_u64(b);
     // fibbonaci_handler.rs:13-27 semantics: after `steps` rounds the result is f_{steps} of the (a, b) sequence
     Fr x = fa, y = fb, res = steps == 0 ? Fr::zero() : fb;
@@ -425,93 +457,164 @@ int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit 
 
 // MatrixCircuit::new(matrix_a, matrix_b, hash_a, hash_b, hash_c) with the hashes computed natively as the handler does
 // (matrix_proof.rs:104-125).  a, b: n*n u64 entries, row-major.
-int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_circuit **out) {
-    if (!out || !a || !b || n == 0 || n > 1024) return ZKG16_ERR_BAD_ARG;
-    auto c = new (std::nothrow) zkg16_circuit();
-    if (!c) return ZKG16_ERR_OOM;
+// The three hash gadgets do not depend on each other, so the circuit is built as segments in arkworks' allocation order —
+// [inputs a, b + matrix witnesses] [hash_a gadget] [hash_b gadget] [two equalities] [matrix_mul + hash_c gadget] [input c +
+// equality] — with the hash_a and hash_b segments on their own threads; each segment numbers its witnesses from the offset
+// the earlier ones will have used (poseidon_hash_witnesses).  ZKG16_SYNTH_THREADS=0 builds them one after another.
+static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, const uint64_t *b, bool threaded) {
+    const size_t nn = n * n;
+    std::vector<Fr> av(nn), bv(nn), cv(nn, Fr::zero());
+    for (size_t i = 0; i < nn; i++) { av[i] = fr_from_u64(a[i]); bv[i] = fr_from_u64(b[i]); }
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) {
+            Fr s = Fr::zero();
+            for (size_t k = 0; k < n; k++) s = fp_add(s, fp_mul(av[i * n + k], bv[k * n + j]));
+            cv[i * n + j] = s;
+        }
+    // generate_constraints (constraints.rs:101-128)
+    Circuit &head = c->add_segment(0);
+    std::vector<Lc> ma(nn), mb(nn);
+    Fr hash_a, hash_b, hash_c;
+    Lc ha, hb, hc;
+    const size_t hw = threaded ? poseidon_hash_witnesses(nn) : 0;
+    Circuit &seg_a = c->add_segment(2 * nn);
+    Circuit &seg_b = c->add_segment(2 * nn + hw);
+    Circuit &seg_mid = c->add_segment(0);
+    Circuit &seg_c = c->add_segment(2 * nn + 2 * hw);
+    Circuit &seg_tail = c->add_segment(0);
+    std::exception_ptr err_a, err_b, err_c;
+    auto build_a = [&]() {
+        try {
+            hash_a = poseidon_hash_native(av.data(), nn);
+            ha = poseidon_hash_gadget(seg_a, ma);
+        } catch (...) { err_a = std::current_exception(); g_terms = true; }
+    };
+    auto build_b = [&]() {
+        try {
+            hash_b = poseidon_hash_native(bv.data(), nn);
+            hb = poseidon_hash_gadget(seg_b, mb);
+        } catch (...) { err_b = std::current_exception(); g_terms = true; }
+    };
+    // the inputs come first in arkworks' order, but their values (the native hashes) are only needed at the end: the
+    // instance slots are reserved now and filled after the builders have produced them
+    Lc in_a = head.new_input(Fr::zero()), in_b = head.new_input(Fr::zero());
+    for (size_t i = 0; i < nn; i++) ma[i] = head.new_witness(av[i]);
+    for (size_t i = 0; i < nn; i++) mb[i] = head.new_witness(bv[i]);
+    std::thread ta, tb;
+    if (threaded) {
+        ta = std::thread(build_a);
+        tb = std::thread(build_b);
+    } else {            // one after another: every segment starts where the previous one actually ended
+        build_a();
+        seg_b.wit_base = seg_a.next_wit();
+        build_b();
+        seg_c.wit_base = seg_b.next_wit();
+    }
+    // matrix_mul (constraints.rs:78-99) + the hash of the product, on this thread
     try {
-        Circuit &cs = c->cs;
-        const size_t nn = n * n;
-        std::vector<Fr> av(nn), bv(nn), cv(nn, Fr::zero());
-        for (size_t i = 0; i < nn; i++) { av[i] = fr_from_u64(a[i]); bv[i] = fr_from_u64(b[i]); }
-        for (size_t i = 0; i < n; i++)
-            for (size_t j = 0; j < n; j++) {
-                Fr s = Fr::zero();
-                for (size_t k = 0; k < n; k++) s = fp_add(s, fp_mul(av[i * n + k], bv[k * n + j]));
-                cv[i * n + j] = s;
-            }
-        const Fr hash_a = poseidon_hash_native(av.data(), nn), hash_b = poseidon_hash_native(bv.data(), nn),
-                 hash_c = poseidon_hash_native(cv.data(), nn);
-        // generate_constraints (constraints.rs:101-128)
-        Lc in_a = cs.new_input(hash_a), in_b = cs.new_input(hash_b);
-        std::vector<Lc> ma(nn), mb(nn);
-        for (size_t i = 0; i < nn; i++) ma[i] = cs.new_witness(av[i]);
-        for (size_t i = 0; i < nn; i++) mb[i] = cs.new_witness(bv[i]);
-        Lc ha = poseidon_hash_gadget(cs, ma);
-        Lc hb = poseidon_hash_gadget(cs, mb);
-        cs.enforce_equal(ha, in_a);
-        cs.enforce_equal(hb, in_b);
-        // matrix_mul (constraints.rs:78-99)
+        hash_c = poseidon_hash_native(cv.data(), nn);
         std::vector<Lc> mc(nn);
-        for (size_t i = 0; i < nn; i++) mc[i] = cs.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
+        for (size_t i = 0; i < nn; i++) mc[i] = seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
         for (size_t i = 0; i < n; i++)
             for (size_t j = 0; j < n; j++) {
-                Lc sum = cs.new_witness(Fr::zero());
+                Lc sum = seg_c.new_witness(Fr::zero());
                 for (size_t k = 0; k < n; k++) {
                     const Lc &ij = ma[i * n + k], &jk = mb[k * n + j];
-                    Lc product = cs.mul(ij, jk);            // `*`: product witness + constraint (:91)
-                    sum = Circuit::add(sum, product);       // symbolic (:92)
-                    cs.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
+                    Lc product = seg_c.mul(ij, jk);            // `*`: product witness + constraint (:91)
+                    sum = Circuit::add(sum, product);          // symbolic (:92)
+                    seg_c.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
                 }
                 mc[i * n + j] = sum;
             }
-        Lc hc = poseidon_hash_gadget(cs, mc);
-        Lc in_c = cs.new_input(hash_c);
-        cs.enforce_equal(hc, in_c);
-    } catch (const std::bad_alloc &) {
-        g_terms = true;
-        delete c;
-        return ZKG16_ERR_OOM;
-    } catch (const std::exception &) {      // a template replay that did not line up: a bug, never a property of the input
-        g_terms = true;
-        delete c;
-        return ZKG16_ERR_UNSUPPORTED;
+        hc = poseidon_hash_gadget(seg_c, mc);
+    } catch (...) { err_c = std::current_exception(); g_terms = true; }
+    if (threaded) { ta.join(); tb.join(); }
+    for (const std::exception_ptr &e : {err_a, err_b, err_c})
+        if (e) std::rethrow_exception(e);
+    if (seg_b.wit_base != seg_a.next_wit() || seg_c.wit_base != seg_b.next_wit()) throw std::logic_error("matrix circuit: segment offsets do not line up");
+    head.instance[1] = hash_a;
+    head.instance[2] = hash_b;
+    in_a.val = hash_a;
+    in_b.val = hash_b;
+    seg_mid.enforce_equal(ha, in_a);
+    seg_mid.enforce_equal(hb, in_b);
+    Lc in_c = head.new_input(hash_c);
+    seg_tail.enforce_equal(hc, in_c);
+}
+
+int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_circuit **out) {
+    if (!out || !a || !b || n == 0 || n > 1024) return ZKG16_ERR_BAD_ARG;
+    const char *env = getenv("ZKG16_SYNTH_THREADS");
+    bool threaded = n >= 2 && !(env && env[0] == '0');
+    for (;;) {
+        auto c = new (std::nothrow) zkg16_circuit();
+        if (!c) return ZKG16_ERR_OOM;
+        try {
+            build_matrix_circuit(c, n, a, b, threaded);
+            *out = c;
+            return ZKG16_OK;
+        } catch (const std::bad_alloc &) {
+            g_terms = true;
+            delete c;
+            return ZKG16_ERR_OOM;
+        } catch (const std::exception &) {
+            g_terms = true;
+            delete c;
+            if (!threaded) return ZKG16_ERR_UNSUPPORTED;      // a template replay that did not line up: a bug, never a property of the input
+            threaded = false;                                  // predicted segment offsets were off: build in order instead
+        }
     }
-    *out = c;
-    return ZKG16_OK;
 }
 
 void zkg16_circuit_free(zkg16_circuit *c) { delete c; }
 
 int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]) {
-    if (!c) return ZKG16_ERR_BAD_ARG;
-    if (num_instance) *num_instance = c->cs.instance.size();
-    if (num_witness) *num_witness = c->cs.witness.size();
-    if (num_constraints) *num_constraints = c->cs.rows[0].size();
+    if (!c || c->segs.empty()) return ZKG16_ERR_BAD_ARG;
+    if (num_instance) *num_instance = c->head().instance.size();
+    if (num_witness) *num_witness = c->num_witness();
+    size_t rows = 0, k[3] = {0, 0, 0};
+    for (const auto &sg : c->segs) {
+        rows += sg->rows[0].size();
+        for (int m = 0; m < 3; m++) k[m] += sg->rows[m].t.size();
+    }
+    if (num_constraints) *num_constraints = rows;
     if (nnz)
-        for (int m = 0; m < 3; m++) nnz[m] = c->cs.rows[m].t.size();
+        for (int m = 0; m < 3; m++) nnz[m] = k[m];
     return ZKG16_OK;
 }
 
-int zkg16_circuit_is_satisfied(const zkg16_circuit *c) { return c ? (c->cs.satisfied() ? 1 : 0) : 0; }
+int zkg16_circuit_is_satisfied(const zkg16_circuit *c) {
+    if (!c || c->segs.empty()) return 0;
+    const std::vector<Fr> w = c->flat_witness();
+    for (const auto &sg : c->segs)
+        if (!sg->satisfied(c->head().instance, w)) return 0;
+    return 1;
+}
 
 // ConstraintMatrices as CSR (caller-allocated: row_ptr[m] has num_constraints + 1 entries, col/coeff nnz[m]) and the
 // full assignment z = instance || witness (Montgomery limbs).
 int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3], uint64_t *z) {
-    if (!c || !row_ptr || !col || !coeff || !z) return ZKG16_ERR_BAD_ARG;
-    const size_t ni = c->cs.instance.size();
+    if (!c || c->segs.empty() || !row_ptr || !col || !coeff || !z) return ZKG16_ERR_BAD_ARG;
+    const size_t ni = c->head().instance.size();
     for (int m = 0; m < 3; m++) {
-        const Circuit::Rows &r = c->cs.rows[m];
-        memcpy(row_ptr[m], r.ptr.data(), r.ptr.size() * sizeof(uint64_t));
-        // instance columns first, then witnesses (ids are already ordered that way within a row)
-        for (size_t k = 0; k < r.t.size(); k++) {
-            const Term &t = r.t[k];
-            col[m][k] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
-            memcpy(coeff[m] + 4 * k, t.c.l, 32);
+        size_t row = 0, k = 0;
+        row_ptr[m][0] = 0;
+        for (const auto &sg : c->segs) {
+            const Circuit::Rows &r = sg->rows[m];
+            for (size_t i = 1; i < r.ptr.size(); i++) row_ptr[m][row + i] = k + r.ptr[i];
+            // instance columns first, then witnesses (ids are already ordered that way within a row)
+            for (size_t j = 0; j < r.t.size(); j++) {
+                const Term &t = r.t[j];
+                col[m][k + j] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
+                memcpy(coeff[m] + 4 * (k + j), t.c.l, 32);
+            }
+            row += r.size();
+            k += r.t.size();
         }
     }
-    memcpy(z, c->cs.instance.data(), ni * 32);
-    memcpy(z + 4 * ni, c->cs.witness.data(), c->cs.witness.size() * 32);
+    memcpy(z, c->head().instance.data(), ni * 32);
+    for (const auto &sg : c->segs)
+        if (!sg->witness.empty()) memcpy(z + 4 * (ni + sg->wit_base), sg->witness.data(), sg->witness.size() * 32);
     return ZKG16_OK;
 }
 
