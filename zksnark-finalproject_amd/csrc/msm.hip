@@ -642,7 +642,7 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     if (!slot.acc_done) {
         ZK_HIP(hipEventCreateWithFlags(&slot.acc_done, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&slot.red_done, hipEventDisableTiming));
-        ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+        if (!slot.stream) ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     }
     slot.buckets.ensure(tb * psz);
     const size_t nseg = FieldTraits<F>::g2 ? plan.lanes_g2 : plan.lanes_g1;      // lanes of one resident round
