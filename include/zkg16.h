@@ -198,7 +198,13 @@ ZKG16_API int zkg16_kernel_timing(zkg16_ctx *ctx, int enable);
 ZKG16_API int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms,
                        double *units /* kernel-specific work units, e.g. bucket additions */);
 ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
-/* Tuning knobs (0 = default): MSM window bits c. */
+/* Tuning / A-B switches; none of them changes a result (tests/test_gpu_parity.py toggles every one and compares proofs).
+ *   "window_bits"    MSM window bits c for every plan (0 = by size: 13 / 15 / 16)      "window_bits_h"  the H MSM's plan only
+ *   "reduce_chunk"   buckets per lane in the bucket reduction (0 = 8)                   "reduce_mode"    1 = work-efficient two-level form
+ *   "wm_concurrent"  0 = witness map in order on the main stream (default: own stream)  "fixup_aux"      1 = fix-ups on the reduction stream
+ *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
+ *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
+ * Unknown names return ZKG16_ERR_UNSUPPORTED. */
 ZKG16_API int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus
