@@ -279,6 +279,14 @@ def main():
                                  "instructions) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command "
                                  "(bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
+        # the bound that does apply: mixed additions per second against the same addition in a bare register-resident loop
+        # (tools/microbench.hip, profiles/microbench_r1_uform.txt: 6.75 G add/s at 2 waves/SIMD on this part)
+        tpl = acc["units"] / max(acc["launches"], 1)
+        nwin = 254 // (16 if tpl >= (1 << 20) else 15 if tpl >= (1 << 17) else 13 if tpl >= (1 << 14) else 9) + 1
+        gadd = tpl * nwin / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": 6.75, "unit": "G mixed additions/s", "frac": gadd / 6.75,
+                      "note": "upper estimate of the entry count (terms x windows, zero digits included); peak = the XYZZ mixed "
+                              "addition alone in a register-resident loop at the kernel's occupancy"}
         if in_flight:
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
