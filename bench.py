@@ -283,10 +283,19 @@ def main():
         # (tools/microbench.hip, profiles/microbench_r1_uform.txt: 6.75 G add/s at 2 waves/SIMD on this part)
         tpl = acc["units"] / max(acc["launches"], 1)
         nwin = 254 // (16 if tpl >= (1 << 20) else 15 if tpl >= (1 << 17) else 13 if tpl >= (1 << 14) else 9) + 1
-        gadd = tpl * nwin / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # entries per launch: a scalar 1 gives one entry, a scalar 0 none, everything else one per window (L, A, B1 share
+        # z; H is uniform); averaged over the four G1 launches like avg_ms
+        R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+        one = np.array([((1 << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        zz = np.asarray(z, dtype=np.uint64).reshape(-1, 4)
+        n_one = int(np.all(zz == one, axis=1).sum())
+        n_zero = int(np.all(zz == 0, axis=1).sum())
+        z_entries = ((zz.shape[0] - n_one - n_zero) * nwin + n_one) / nshard
+        h_entries = nh * (254 // (16 if nh >= (1 << 20) else 15 if nh >= (1 << 17) else 13 if nh >= (1 << 14) else 9) + 1)
+        gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": 6.75, "unit": "G mixed additions/s", "frac": gadd / 6.75,
-                      "note": "upper estimate of the entry count (terms x windows, zero digits included); peak = the XYZZ mixed "
-                              "addition alone in a register-resident loop at the kernel's occupancy"}
+                      "note": "entries = one per window for every scalar other than 0 and 1 (B1's density filter not counted: slight "
+                              "over-estimate); peak = the XYZZ mixed addition alone in a register-resident loop at the kernel's occupancy"}
         if in_flight:
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
