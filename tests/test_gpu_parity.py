@@ -127,6 +127,38 @@ def test_msm_random_vs_oracle(dev, oracle, group, n, c):
     assert ginf == einf and np.array_equal(got, exp)
 
 
+def test_msm_randomised_sizes_and_distributions(dev, oracle):
+    """Many (size, scalar width, window bits, run length) combinations against the oracle: the accumulation's segmenting, the
+    short / long / folded fix-up paths and the bucket reduction are exercised at shapes no fixed case pins down.  Each base is
+    [k]G with a known k, so the expected result is one scalar multiplication of the generator (cheap even for large n)."""
+    rng = np.random.default_rng(20261004)
+    to_int = lambda a: [unlimbs(r) for r in a]
+    for trial in range(24):
+        group = "g2" if trial % 6 == 5 else "g1"
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 257, 1000, 4097, 9001, 33333, 70001]))
+        bits = int(rng.choice([1, 2, 8, 15, 16, 17, 31, 64, 128, 254]))
+        pts, inf, logs = _random_points(dev, group, n, 5000 + trial)
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        full, rem = divmod(bits, 64)
+        for i in range(full):
+            sc[:, i] = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+        if rem:
+            sc[:, full] = rng.integers(0, 1 << rem, size=n, dtype=np.uint64)
+        if trial % 4 == 1:
+            sc[rng.integers(0, n, size=max(1, n // 3))] = 0            # holes
+        c = int(rng.choice([0, 0, 4, 7, 10, 13, 16]))
+        seg = int(rng.choice([0, 0, 1, 3, 50]))
+        dev.set_option("window_bits", c)
+        dev.set_option("min_seg", seg)
+        got, ginf = dev.msm(group, pts, sc, inf)
+        dev.set_option("window_bits", 0)
+        dev.set_option("min_seg", 0)
+        total = sum(s * k for s, k in zip(to_int(sc), to_int(logs))) % P.R_MOD
+        gen = G1_GEN_LIMBS if group == "g1" else G2_GEN_LIMBS
+        exp, einf = oracle.point_mul(group, gen, fr_canon(total))
+        assert ginf == einf and np.array_equal(got, exp), (trial, group, n, bits, c, seg)
+
+
 @pytest.mark.parametrize("kind", ["ones", "bits", "same", "matmul_mix", "top_digit"])
 def test_msm_skewed_scalars(dev, oracle, kind):
     """Scalar distributions of the reference's witnesses: ~10% ones, zeros, bit vectors —
