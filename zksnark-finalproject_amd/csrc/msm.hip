@@ -701,7 +701,9 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
         slot.fixups_pending = false;
     }
     const char *rname = FieldTraits<F>::g2 ? "msm_reduce_g2" : "msm_reduce_g1";
-    int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : 8;
+    // buckets per lane: 8 when the reduction has enough lanes to matter as work; fewer when it is a short, purely
+    // latency-bound chain (small circuits, 1/8 shards): measured 4.4 -> 3.7 ms at 6,476 constraints, 5.6 -> 5.1 ms at 60,684
+    int kk = ctx->opt_reduce_chunk > 0 ? ctx->opt_reduce_chunk : (tb <= 16384 ? 2 : tb <= 131072 ? 4 : 8);
     while ((size_t)kk > plan.nb) kk >>= 1;
     const size_t nchunks = plan.nb / kk;
     const size_t tot = nchunks * plan.nwin;
