@@ -226,5 +226,10 @@ void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out
 // device outputs; either may be null: saturated (arkworks layout, host-bound) and/or unsaturated (device-resident key)
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out_sat, G1AffineU *out_u = nullptr);
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out_sat, G2AffineU *out_u = nullptr);
+// several scalar ranges in one pass (<= 8): range k = [start[k], start[k+1]) of the n concatenated scalars -> out_u[k] / out_sat[k]
+void fixed_base_g1_multi(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, int nseg, const size_t *start,
+                         G1AffineU *const *out_u, G1Affine *const *out_sat);
+void fixed_base_g2_multi(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, int nseg, const size_t *start,
+                         G2AffineU *const *out_u, G2Affine *const *out_sat);
 
 }  // namespace zk

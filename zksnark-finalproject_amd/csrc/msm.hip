@@ -490,12 +490,22 @@ fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XY
     stv(out + i, acc);
 }
 
+// outputs of one batched to-affine: consecutive index ranges [start[k], start[k+1]) go to their own arrays, each in the
+// unsaturated (device-resident key) and / or arkworks' saturated form; several queries of a setup share one launch this way
+template <class FU>
+struct AffineSegs {
+    int n;
+    size_t start[8];
+    Affine<FU> *out_u[8];
+    Affine<typename FieldTraits<FU>::Sat> *out_sat[8];
+};
+
 // XYZZ -> affine for n points; thread t owns points t, t + T, t + 2T, ... (T = threads launched) so that a wave touches
 // neighbouring points at every step.  `pref` is n field elements of scratch.  Either output may be null:
 // out_u = unsaturated (device-resident key), out_sat = arkworks' saturated Montgomery form (host-bound).
 template <class FU>
 __global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
-batch_affine_kernel(const XYZZ<FU> *pts, size_t n, FU *pref, Affine<FU> *out_u, Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+batch_affine_kernel(const XYZZ<FU> *pts, size_t n, FU *pref, AffineSegs<FU> segs) {
     using FS = typename FieldTraits<FU>::Sat;
     const size_t T = (size_t)gridDim.x * blockDim.x;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,11 +528,14 @@ batch_affine_kernel(const XYZZ<FU> *pts, size_t n, FU *pref, Affine<FU> *out_u, 
             o.x = f_tidy(f_mul(p.x, f_mul(dinv, p.zzz)));         // X / ZZ
             o.y = f_tidy(f_mul(p.y, f_mul(dinv, p.zz)));          // Y / ZZZ
         }
-        if (out_u) stv(out_u + i, o);
-        if (out_sat) {
+        int sg = 0;
+        while (sg + 1 < segs.n && i >= segs.start[sg + 1]) sg++;
+        const size_t j = i - segs.start[sg];
+        if (segs.out_u[sg]) stv(segs.out_u[sg] + j, o);
+        if (segs.out_sat[sg]) {
             Affine<FS> os = Affine<FS>::inf();
             if (!p.is_inf()) os = Affine<FS>{to_sat(o.x), to_sat(o.y)};
-            stv(out_sat + i, os);
+            stv(segs.out_sat[sg] + j, os);
         }
         if (i < T + t) break;       // i == t: first point of this thread
     }
@@ -824,29 +837,43 @@ void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t
 }
 
 template <class FU>
-static void batch_affine_run(zkg16_ctx *ctx, const XYZZ<FU> *pts, size_t n, DevBuf &pref, Affine<FU> *out_u,
-                             Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+static void batch_affine_run(zkg16_ctx *ctx, const XYZZ<FU> *pts, size_t n, DevBuf &pref, const AffineSegs<FU> &segs) {
     // about one wave per SIMD: the serial inversion (~600 products) is amortised over n / threads points
     size_t threads = (size_t)ctx->num_cus * 4 * 64;
     if (threads * 4 > n) threads = (n + 3) / 4;
     const unsigned blocks = (unsigned)((threads + 63) / 64);
     pref.ensure(n * sizeof(FU));
-    hipLaunchKernelGGL(batch_affine_kernel<FU>, dim3(blocks), dim3(64), 0, ctx->stream, pts, n, pref.as<FU>(), out_u, out_sat);
+    hipLaunchKernelGGL(batch_affine_kernel<FU>, dim3(blocks), dim3(64), 0, ctx->stream, pts, n, pref.as<FU>(), segs);
     ZK_HIP(hipGetLastError());
 }
 
-// out_u / out_sat: device pointers, either may be null
+// [s_i] base for the n concatenated scalars; results split over `segs`
 template <class FU>
 static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<typename FieldTraits<FU>::Sat> &base, const Fr *scalars_canonical,
-                           size_t n, Affine<FU> *out_u, Affine<typename FieldTraits<FU>::Sat> *out_sat) {
+                           size_t n, const AffineSegs<FU> &segs) {
     using FS = typename FieldTraits<FU>::Sat;
     if (n == 0) return;
     if (cache.key.size() != sizeof base || memcmp(cache.key.data(), &base, sizeof base) != 0) {
-        std::vector<Affine<FS>> wb(32);
+        // the 32 window bases 2^(8w) * base as affine points, one host inversion for all of them
+        std::vector<XYZZ<FS>> wx(32);
         XYZZ<FS> cur = XYZZ<FS>::from_affine(base);
         for (int w = 0; w < 32; w++) {
-            wb[w] = xyzz_to_affine(cur);
+            wx[w] = cur;
             for (int q = 0; q < 8; q++) cur = xyzz_dbl(cur);
+        }
+        std::vector<Affine<FS>> wb(32, Affine<FS>::inf());
+        std::vector<FS> pre(32);
+        FS acc = FS::one();
+        for (int w = 0; w < 32; w++) {
+            pre[w] = acc;
+            if (!wx[w].is_inf()) acc = f_mul(acc, f_mul(wx[w].zz, wx[w].zzz));
+        }
+        FS inv = f_inv(acc);
+        for (int w = 31; w >= 0; w--) {
+            if (wx[w].is_inf()) continue;
+            const FS dinv = f_mul(inv, pre[w]);
+            inv = f_mul(inv, f_mul(wx[w].zz, wx[w].zzz));
+            wb[w] = Affine<FS>{f_mul(wx[w].x, f_mul(dinv, wx[w].zzz)), f_mul(wx[w].y, f_mul(dinv, wx[w].zz))};
         }
         DevBuf d_wb(32 * sizeof(Affine<FS>)), d_xyzz(32 * 255 * sizeof(XYZZ<FU>));
         cache.table.ensure(32 * 255 * sizeof(Affine<FU>));
@@ -854,7 +881,10 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
         hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
                            d_xyzz.as<XYZZ<FU>>());
         ZK_HIP(hipGetLastError());
-        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, cache.table.as<Affine<FU>>(), nullptr);
+        AffineSegs<FU> ts{};
+        ts.n = 1;
+        ts.out_u[0] = cache.table.as<Affine<FU>>();
+        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, ts);
         ZK_HIP(hipStreamSynchronize(ctx->stream));      // d_wb, d_xyzz go out of scope
         cache.key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
     }
@@ -862,14 +892,33 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
     hipLaunchKernelGGL(fixed_base_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cache.table.as<Affine<FU>>(),
                        reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>());
     ZK_HIP(hipGetLastError());
-    batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, out_u, out_sat);
+    batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, segs);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, G1Affine *out_sat, G1AffineU *out_u) {
-    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, out_u, out_sat);
+    AffineSegs<FqU> s1{};
+    s1.n = 1; s1.out_u[0] = out_u; s1.out_sat[0] = out_sat;
+    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, s1);
 }
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, G2Affine *out_sat, G2AffineU *out_u) {
-    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, out_u, out_sat);
+    AffineSegs<Fq2U> s1{};
+    s1.n = 1; s1.out_u[0] = out_u; s1.out_sat[0] = out_sat;
+    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, s1);
+}
+// several scalar ranges, one pass: scalars are the concatenation of the ranges; range k = [start[k], start[k+1]) -> out_*[k]
+void fixed_base_g1_multi(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, int nseg, const size_t *start, G1AffineU *const *out_u,
+                         G1Affine *const *out_sat) {
+    AffineSegs<FqU> s{};
+    s.n = nseg;
+    for (int k = 0; k < nseg; k++) { s.start[k] = start[k]; s.out_u[k] = out_u[k]; s.out_sat[k] = out_sat[k]; }
+    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, s);
+}
+void fixed_base_g2_multi(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, int nseg, const size_t *start, G2AffineU *const *out_u,
+                         G2Affine *const *out_sat) {
+    AffineSegs<Fq2U> s{};
+    s.n = nseg;
+    for (int k = 0; k < nseg; k++) { s.start[k] = start[k]; s.out_u[k] = out_u[k]; s.out_sat[k] = out_sat[k]; }
+    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, s);
 }
 
 }  // namespace zk

@@ -107,43 +107,6 @@ __global__ void __launch_bounds__(256) setup_lg_kernel(const Fr *u, const Fr *v,
     st_fr(lg + k, fp_mul(x, k < num_instance ? ginv : dinv));
 }
 
-static void points_g1(zkg16_ctx *ctx, const G1Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf,
-                      G1AffineU *resident = nullptr) {
-    if (!n) return;
-    canon.ensure(n * sizeof(Fr));
-    fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
-    if (resident) {                                   // key stays on the device: straight into the unsaturated pk layout
-        fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, nullptr, resident);
-        return;
-    }
-    pts.ensure(n * sizeof(G1Affine));
-    fixed_base_g1_run(ctx, g, canon.as<Fr>(), n, pts.as<G1Affine>());
-    ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (inf) {
-        const G1Affine *o = reinterpret_cast<const G1Affine *>(out);
-        for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
-    }
-}
-static void points_g2(zkg16_ctx *ctx, const G2Affine &g, const Fr *scalars_mont, size_t n, DevBuf &canon, DevBuf &pts, uint64_t *out, uint8_t *inf,
-                      G2AffineU *resident = nullptr) {
-    if (!n) return;
-    canon.ensure(n * sizeof(Fr));
-    fr_from_mont_run(ctx, scalars_mont, canon.as<Fr>(), n);
-    if (resident) {
-        fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, nullptr, resident);
-        return;
-    }
-    pts.ensure(n * sizeof(G2Affine));
-    fixed_base_g2_run(ctx, g, canon.as<Fr>(), n, pts.as<G2Affine>());
-    ZK_HIP(hipMemcpyAsync(out, pts.p, n * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    if (inf) {
-        const G2Affine *o = reinterpret_cast<const G2Affine *>(out);
-        for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
-    }
-}
-
 void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affine &g1, const G2Affine &g2, const SetupOut &out, PkDev *res) {
     const Fr &tau = trap[0], &alpha = trap[1], &beta = trap[2], &gamma = trap[3], &delta = trap[4];
     const size_t N = (size_t)1 << m.log_n, nc = m.num_constraints, ni = m.num_instance, nv = m.num_variables;
@@ -204,20 +167,74 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
         ZK_HIP(hipMemsetAsync(res->l.p, 0, res->l.bytes, ctx->stream));
         ZK_HIP(hipMemsetAsync(res->b2.p, 0, res->b2.bytes, ctx->stream));
     }
-    points_g1(ctx, g1, uvw[0].as<Fr>(), nv, canon, pts, out.a_query, out.a_inf, res ? res->a.as<G1AffineU>() : nullptr);
-    points_g1(ctx, g1, uvw[1].as<Fr>(), nv, canon, pts, out.b_g1_query, out.b_g1_inf, res ? res->b1.as<G1AffineU>() : nullptr);
-    points_g2(ctx, g2, uvw[1].as<Fr>(), nv, canon, pts, out.b_g2_query, out.b_g2_inf, res ? res->b2.as<G2AffineU>() : nullptr);
-    points_g1(ctx, g1, L.as<Fr>(), N - 1, canon, pts, out.h_query, nullptr, res ? res->h.as<G1AffineU>() : nullptr);
-    points_g1(ctx, g1, lg.as<Fr>() + ni, nv - ni, canon, pts, out.l_query, out.l_inf, res ? res->l.as<G1AffineU>() + ni : nullptr);
-    points_g1(ctx, g1, lg.as<Fr>(), ni, canon, pts, out.gamma_abc_g1, nullptr);
     // alpha, beta, delta (G1) ; beta, delta, gamma (G2)
     Fr singles[4] = {alpha, beta, delta, gamma};
     DevBuf d_s(4 * sizeof(Fr));
     ZK_HIP(hipMemcpyAsync(d_s.p, singles, sizeof singles, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t o1[4 * 12], o2[4 * 24];
-    points_g1(ctx, g1, d_s.as<Fr>(), 4, canon, pts, o1, nullptr);
-    points_g2(ctx, g2, d_s.as<Fr>(), 4, canon, pts, o2, nullptr);
+    // One fixed-base pass per group for all of its queries (every pass pays two latency chains whatever its size: the 32
+    // dependent mixed additions per point and the one inversion per thread of the batched to-affine; seven G1 passes and
+    // three G2 passes cost a 1,594-constraint setup 9 of its 15 ms).
+    //   G1: a | b1 | h | l | gamma_abc | alpha, beta, delta, (gamma)        G2: b2 | beta, delta, gamma via (alpha, beta, delta, gamma)
+    {
+        const size_t len[6] = {nv, nv, N - 1, nv - ni, ni, 4};
+        const Fr *src[6] = {uvw[0].as<Fr>(), uvw[1].as<Fr>(), L.as<Fr>(), lg.as<Fr>() + ni, lg.as<Fr>(), d_s.as<Fr>()};
+        size_t start[7] = {0};
+        for (int k = 0; k < 6; k++) start[k + 1] = start[k] + len[k];
+        const size_t total = start[6];
+        canon.ensure(total * sizeof(Fr));
+        for (int k = 0; k < 6; k++)
+            if (len[k]) fr_from_mont_run(ctx, src[k], canon.as<Fr>() + start[k], len[k]);
+        // saturated outputs (host-bound): everything for zkg16_setup, only gamma_abc and the singles for the resident key
+        pts.ensure((res ? ni + 4 : total) * sizeof(G1Affine));
+        G1Affine *sat = pts.as<G1Affine>();
+        G1AffineU *ou[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        G1Affine *os[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (res) {
+            ou[0] = res->a.as<G1AffineU>(); ou[1] = res->b1.as<G1AffineU>(); ou[2] = res->h.as<G1AffineU>(); ou[3] = res->l.as<G1AffineU>() + ni;
+            os[4] = sat; os[5] = sat + ni;
+        } else {
+            for (int k = 0; k < 6; k++) os[k] = sat + start[k];
+        }
+        fixed_base_g1_multi(ctx, g1, canon.as<Fr>(), total, 6, start, ou, os);
+        auto fetch = [&](const G1Affine *dsrc, size_t n, uint64_t *dst, uint8_t *inf) {
+            if (!n) return;
+            ZK_HIP(hipMemcpyAsync(dst, dsrc, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            if (inf) {
+                const G1Affine *o = reinterpret_cast<const G1Affine *>(dst);
+                for (size_t i = 0; i < n; i++) inf[i] = o[i].is_inf() ? 1 : 0;
+            }
+        };
+        if (!res) {
+            fetch(os[0], nv, out.a_query, out.a_inf);
+            fetch(os[1], nv, out.b_g1_query, out.b_g1_inf);
+            fetch(os[2], N - 1, out.h_query, nullptr);
+            fetch(os[3], nv - ni, out.l_query, out.l_inf);
+        }
+        fetch(os[4], ni, out.gamma_abc_g1, nullptr);
+        fetch(os[5], 4, o1, nullptr);
+    }
+    {
+        const size_t len[2] = {nv, 4};
+        const Fr *src[2] = {uvw[1].as<Fr>(), d_s.as<Fr>()};
+        const size_t start[3] = {0, nv, nv + 4};
+        canon.ensure((nv + 4) * sizeof(Fr));
+        for (int k = 0; k < 2; k++) fr_from_mont_run(ctx, src[k], canon.as<Fr>() + start[k], len[k]);
+        pts.ensure((res ? 4 : nv + 4) * sizeof(G2Affine));
+        G2Affine *sat = pts.as<G2Affine>();
+        G2AffineU *ou[2] = {res ? res->b2.as<G2AffineU>() : nullptr, nullptr};
+        G2Affine *os[2] = {res ? nullptr : sat, res ? sat : sat + nv};
+        fixed_base_g2_multi(ctx, g2, canon.as<Fr>(), nv + 4, 2, start, ou, os);
+        if (!res) {
+            ZK_HIP(hipMemcpyAsync(out.b_g2_query, os[0], nv * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+            const G2Affine *o = reinterpret_cast<const G2Affine *>(out.b_g2_query);
+            for (size_t i = 0; i < nv; i++) out.b_g2_inf[i] = o[i].is_inf() ? 1 : 0;
+        }
+        ZK_HIP(hipMemcpyAsync(o2, os[1], 4 * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     if (res) {
         memcpy(&res->alpha_g1, o1, 96); memcpy(&res->beta_g1, o1 + 12, 96); memcpy(&res->delta_g1, o1 + 24, 96);
         memcpy(&res->beta_g2, o2 + 24, 192); memcpy(&res->delta_g2, o2 + 48, 192);
