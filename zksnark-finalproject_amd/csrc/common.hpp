@@ -64,8 +64,11 @@ struct DevBuf {
 
 // fixed-base scalar multiplication (setup): window table of the last generator used + scratch, kept across calls
 struct FixedBaseCache {
-    std::vector<uint8_t> key;      // the generator's bytes
-    DevBuf table, sums, pref;
+    // window tables of the two most recently used generators (a request uses the standard generator to derive its own
+    // random one, then that one for the whole key) + scratch shared by both
+    struct Entry { std::vector<uint8_t> key; DevBuf table; uint64_t stamp = 0; } e[2];
+    uint64_t clock = 0;
+    DevBuf sums, pref;
 };
 
 // Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg reads these).

@@ -853,7 +853,13 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
                            size_t n, const AffineSegs<FU> &segs) {
     using FS = typename FieldTraits<FU>::Sat;
     if (n == 0) return;
-    if (cache.key.size() != sizeof base || memcmp(cache.key.data(), &base, sizeof base) != 0) {
+    FixedBaseCache::Entry *ent = nullptr;
+    for (auto &x : cache.e)
+        if (x.key.size() == sizeof base && memcmp(x.key.data(), &base, sizeof base) == 0) ent = &x;
+    const bool miss = ent == nullptr;
+    if (miss) ent = cache.e[0].stamp <= cache.e[1].stamp ? &cache.e[0] : &cache.e[1];      // replace the older one
+    ent->stamp = ++cache.clock;
+    if (miss) {
         // the 32 window bases 2^(8w) * base as affine points, one host inversion for all of them
         std::vector<XYZZ<FS>> wx(32);
         XYZZ<FS> cur = XYZZ<FS>::from_affine(base);
@@ -876,20 +882,20 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
             wb[w] = Affine<FS>{f_mul(wx[w].x, f_mul(dinv, wx[w].zzz)), f_mul(wx[w].y, f_mul(dinv, wx[w].zz))};
         }
         DevBuf d_wb(32 * sizeof(Affine<FS>)), d_xyzz(32 * 255 * sizeof(XYZZ<FU>));
-        cache.table.ensure(32 * 255 * sizeof(Affine<FU>));
+        ent->table.ensure(32 * 255 * sizeof(Affine<FU>));
         ZK_HIP(hipMemcpyAsync(d_wb.p, wb.data(), 32 * sizeof(Affine<FS>), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
                            d_xyzz.as<XYZZ<FU>>());
         ZK_HIP(hipGetLastError());
         AffineSegs<FU> ts{};
         ts.n = 1;
-        ts.out_u[0] = cache.table.as<Affine<FU>>();
+        ts.out_u[0] = ent->table.as<Affine<FU>>();
         batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, ts);
         ZK_HIP(hipStreamSynchronize(ctx->stream));      // d_wb, d_xyzz go out of scope
-        cache.key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
+        ent->key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
     }
     cache.sums.ensure(n * sizeof(XYZZ<FU>));
-    hipLaunchKernelGGL(fixed_base_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cache.table.as<Affine<FU>>(),
+    hipLaunchKernelGGL(fixed_base_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ent->table.as<Affine<FU>>(),
                        reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>());
     ZK_HIP(hipGetLastError());
     batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, segs);
