@@ -179,6 +179,10 @@ ZKG16_API int zkg16_fixed_base_g1(zkg16_ctx *ctx, const uint64_t base[12], const
                         uint64_t *out_affine /* n x 12 */, uint8_t *out_inf /* n */);
 ZKG16_API int zkg16_fixed_base_g2(zkg16_ctx *ctx, const uint64_t base[24], const uint64_t *scalars_canonical, size_t n,
                         uint64_t *out_affine /* n x 24 */, uint8_t *out_inf /* n */);
+/* One scalar multiplication on the host (no ctx, no GPU): [k] base, k canonical.  What a caller uses to derive its own
+ * generators (upstream: `E::G1::rand`), where a device pass would be all latency. */
+ZKG16_API int zkg16_scalar_mul_g1(const uint64_t base[12], const uint64_t k_canonical[4], uint64_t out_affine[12], uint8_t *out_inf);
+ZKG16_API int zkg16_scalar_mul_g2(const uint64_t base[24], const uint64_t k_canonical[4], uint64_t out_affine[24], uint8_t *out_inf);
 
 /* ---- device-resident stage benches (inputs uploaded once, op repeated on device) ---------------- */
 ZKG16_API int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int iters, float *ms_per_iter);

@@ -40,6 +40,8 @@ SIGNATURES = {
     "zkg16_combine_partials": (C.c_int, [u64p, u64p, u64p, u64p, u64p, u64p, u8p, C.c_int, u64p, u8p]),
     "zkg16_setup": (C.c_int, [ctxp, H, u64p, u64p, u64p, u64p, vp, u64p, vp, u64p, vp, vp, vp, vp, u64p, u64p, u64p, u64p, u64p, u64p, u64p]),
     "zkg16_setup_resident": (C.c_int, [ctxp, H, u64p, u64p, u64p, C.POINTER(H), u64p, u64p, u64p, u64p, u64p]),
+    "zkg16_scalar_mul_g1": (C.c_int, [u64p, u64p, u64p, C.POINTER(C.c_uint8)]),
+    "zkg16_scalar_mul_g2": (C.c_int, [u64p, u64p, u64p, C.POINTER(C.c_uint8)]),
     "zkg16_pairing_check": (C.c_int, [u64p, u8p, u64p, u8p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
     "zkg16_verify": (C.c_int, [u64p, u64p, u64p, u64p, u64p, sz, vp, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),

@@ -270,6 +270,25 @@ int zkg16_pairing_check(const uint64_t *g1, const uint8_t *g1_inf, const uint64_
     return ZKG16_OK;
 }
 
+int zkg16_scalar_mul_g1(const uint64_t base[12], const uint64_t k_canonical[4], uint64_t out_affine[12], uint8_t *out_inf) {
+    if (!base || !k_canonical || !out_affine) return ZKG16_ERR_BAD_ARG;
+    Fr k;
+    memcpy(&k, k_canonical, sizeof k);
+    const G1Affine r = xyzz_to_affine(xyzz_mul(G1XYZZ::from_affine(load_pt<G1Affine>(base, 0)), k.l));
+    memcpy(out_affine, &r, sizeof r);
+    if (out_inf) *out_inf = r.is_inf() ? 1 : 0;
+    return ZKG16_OK;
+}
+int zkg16_scalar_mul_g2(const uint64_t base[24], const uint64_t k_canonical[4], uint64_t out_affine[24], uint8_t *out_inf) {
+    if (!base || !k_canonical || !out_affine) return ZKG16_ERR_BAD_ARG;
+    Fr k;
+    memcpy(&k, k_canonical, sizeof k);
+    const G2Affine r = xyzz_to_affine(xyzz_mul(G2XYZZ::from_affine(load_pt<G2Affine>(base, 0)), k.l));
+    memcpy(out_affine, &r, sizeof r);
+    if (out_inf) *out_inf = r.is_inf() ? 1 : 0;
+    return ZKG16_OK;
+}
+
 // e(A, B) == e(alpha, beta) * e(sum_i z_i gamma_abc_i, gamma) * e(C, delta) ?
 // gamma_abc_g1: num_instance points (the first pairs with the constant 1); public_inputs: (num_instance - 1) Montgomery Fr.
 int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t gamma_g2[24], const uint64_t delta_g2[24],

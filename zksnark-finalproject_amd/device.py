@@ -279,3 +279,16 @@ def pairing_check(g1_points, g2_points, g1_inf=None, g2_inf=None, plain_final_ex
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     return bool(ok.value)
+
+
+def scalar_mul(group, base, k_canonical):
+    """[k] base on the host (zkg16_scalar_mul_g1/g2) -> (affine limbs, inf)."""
+    lib = _lib.load()
+    w = 12 if group == "g1" else 24
+    out = np.zeros(w, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    fn = lib.zkg16_scalar_mul_g1 if group == "g1" else lib.zkg16_scalar_mul_g2
+    rc = fn(_u64(base).reshape(-1), _u64(k_canonical).reshape(-1), out, C.byref(inf))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return out, int(inf.value)

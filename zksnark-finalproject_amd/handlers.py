@@ -23,9 +23,10 @@ def _fr_mont(x):
 def _setup_and_prove(dev, circ, rng, keep_key=False):
     trap = np.stack([_fr_mont(rng.randrange(1, R_MOD)) for _ in range(5)])
     # arkworks draws random generators; any subgroup generator gives a valid key: [k]G for random k
-    k = np.stack([np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)])
-    g1 = dev.fixed_base("g1", g1_generator(), k)[0][0]
-    g2 = dev.fixed_base("g2", g2_generator(), k)[0][0]
+    from .device import scalar_mul
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    g1 = scalar_mul("g1", g1_generator(), k)[0]
+    g2 = scalar_mul("g2", g2_generator(), k)[0]
     rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
     t0 = time.perf_counter()
     if keep_key:        # tests want the key on the host as well
