@@ -68,7 +68,7 @@ struct FixedBaseCache {
     // random one, then that one for the whole key) + scratch shared by both
     struct Entry { std::vector<uint8_t> key; DevBuf table; uint64_t stamp = 0; } e[2];
     uint64_t clock = 0;
-    DevBuf sums, pref;
+    DevBuf sums, pref, win_bases, table_xyzz;
 };
 
 // Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg reads these).
@@ -230,9 +230,10 @@ void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out_sat, G1AffineU *out_u = nullptr);
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out_sat, G2AffineU *out_u = nullptr);
 // several scalar ranges in one pass (<= 8): range k = [start[k], start[k+1]) of the n concatenated scalars -> out_u[k] / out_sat[k]
+// sync = false: everything is left queued on ctx->stream (the caller synchronises before touching the outputs)
 void fixed_base_g1_multi(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, int nseg, const size_t *start,
-                         G1AffineU *const *out_u, G1Affine *const *out_sat);
+                         G1AffineU *const *out_u, G1Affine *const *out_sat, bool sync = true);
 void fixed_base_g2_multi(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, int nseg, const size_t *start,
-                         G2AffineU *const *out_u, G2Affine *const *out_sat);
+                         G2AffineU *const *out_u, G2Affine *const *out_sat, bool sync = true);
 
 }  // namespace zk

@@ -850,7 +850,7 @@ static void batch_affine_run(zkg16_ctx *ctx, const XYZZ<FU> *pts, size_t n, DevB
 // [s_i] base for the n concatenated scalars; results split over `segs`
 template <class FU>
 static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<typename FieldTraits<FU>::Sat> &base, const Fr *scalars_canonical,
-                           size_t n, const AffineSegs<FU> &segs) {
+                           size_t n, const AffineSegs<FU> &segs, bool sync = true) {
     using FS = typename FieldTraits<FU>::Sat;
     if (n == 0) return;
     FixedBaseCache::Entry *ent = nullptr;
@@ -881,9 +881,11 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
             inv = f_mul(inv, f_mul(wx[w].zz, wx[w].zzz));
             wb[w] = Affine<FS>{f_mul(wx[w].x, f_mul(dinv, wx[w].zzz)), f_mul(wx[w].y, f_mul(dinv, wx[w].zz))};
         }
-        DevBuf d_wb(32 * sizeof(Affine<FS>)), d_xyzz(32 * 255 * sizeof(XYZZ<FU>));
+        DevBuf &d_wb = cache.win_bases, &d_xyzz = cache.table_xyzz;      // kept in the cache: nothing here has to outlive a sync
+        d_wb.ensure(32 * sizeof(Affine<FS>));
+        d_xyzz.ensure(32 * 255 * sizeof(XYZZ<FU>));
         ent->table.ensure(32 * 255 * sizeof(Affine<FU>));
-        ZK_HIP(hipMemcpyAsync(d_wb.p, wb.data(), 32 * sizeof(Affine<FS>), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpy(d_wb.p, wb.data(), 32 * sizeof(Affine<FS>), hipMemcpyHostToDevice));       // 3-6 KB, from a host vector that goes away
         hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
                            d_xyzz.as<XYZZ<FU>>());
         ZK_HIP(hipGetLastError());
@@ -891,7 +893,6 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
         ts.n = 1;
         ts.out_u[0] = ent->table.as<Affine<FU>>();
         batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, ts);
-        ZK_HIP(hipStreamSynchronize(ctx->stream));      // d_wb, d_xyzz go out of scope
         ent->key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
     }
     cache.sums.ensure(n * sizeof(XYZZ<FU>));
@@ -899,7 +900,7 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
                        reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>());
     ZK_HIP(hipGetLastError());
     batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, segs);
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (sync) ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, G1Affine *out_sat, G1AffineU *out_u) {
     AffineSegs<FqU> s1{};
@@ -913,18 +914,18 @@ void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_
 }
 // several scalar ranges, one pass: scalars are the concatenation of the ranges; range k = [start[k], start[k+1]) -> out_*[k]
 void fixed_base_g1_multi(zkg16_ctx *ctx, const G1Affine &base, const Fr *sc, size_t n, int nseg, const size_t *start, G1AffineU *const *out_u,
-                         G1Affine *const *out_sat) {
+                         G1Affine *const *out_sat, bool sync) {
     AffineSegs<FqU> s{};
     s.n = nseg;
     for (int k = 0; k < nseg; k++) { s.start[k] = start[k]; s.out_u[k] = out_u[k]; s.out_sat[k] = out_sat[k]; }
-    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, s);
+    fixed_base_run<FqU>(ctx, ctx->fb_g1, base, sc, n, s, sync);
 }
 void fixed_base_g2_multi(zkg16_ctx *ctx, const G2Affine &base, const Fr *sc, size_t n, int nseg, const size_t *start, G2AffineU *const *out_u,
-                         G2Affine *const *out_sat) {
+                         G2Affine *const *out_sat, bool sync) {
     AffineSegs<Fq2U> s{};
     s.n = nseg;
     for (int k = 0; k < nseg; k++) { s.start[k] = start[k]; s.out_u[k] = out_u[k]; s.out_sat[k] = out_sat[k]; }
-    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, s);
+    fixed_base_run<Fq2U>(ctx, ctx->fb_g2, base, sc, n, s, sync);
 }
 
 }  // namespace zk

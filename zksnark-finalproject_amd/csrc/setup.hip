@@ -176,6 +176,35 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
     // dependent mixed additions per point and the one inversion per thread of the batched to-affine; seven G1 passes and
     // three G2 passes cost a 1,594-constraint setup 9 of its 15 ms).
     //   G1: a | b1 | h | l | gamma_abc | alpha, beta, delta, (gamma)        G2: b2 | beta, delta, gamma via (alpha, beta, delta, gamma)
+    // The G2 pass is queued on the second stream first, the G1 pass on the main stream: their latency chains overlap.
+    DevBuf canon2, pts2;
+    G2Affine *g2_sat[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr;
+    ZK_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    ZK_HIP(hipEventRecord(ev_in, ctx->stream));                  // uvw, lg, L, d_s are ready on the main stream
+    ZK_HIP(hipStreamWaitEvent(ctx->wm_stream, ev_in, 0));
+    {
+        const size_t len[2] = {nv, 4};
+        const Fr *src[2] = {uvw[1].as<Fr>(), d_s.as<Fr>()};
+        const size_t start[3] = {0, nv, nv + 4};
+        canon2.ensure((nv + 4) * sizeof(Fr));
+        pts2.ensure((res ? 4 : nv + 4) * sizeof(G2Affine));
+        G2Affine *sat = pts2.as<G2Affine>();
+        G2AffineU *ou[2] = {res ? res->b2.as<G2AffineU>() : nullptr, nullptr};
+        g2_sat[0] = res ? nullptr : sat;
+        g2_sat[1] = res ? sat : sat + nv;
+        std::swap(ctx->stream, ctx->wm_stream);                  // every launch helper targets ctx->stream
+        try {
+            for (int k = 0; k < 2; k++) fr_from_mont_run(ctx, src[k], canon2.as<Fr>() + start[k], len[k]);
+            fixed_base_g2_multi(ctx, g2, canon2.as<Fr>(), nv + 4, 2, start, ou, g2_sat, false);
+        } catch (...) {
+            std::swap(ctx->stream, ctx->wm_stream);
+            (void)hipEventDestroy(ev_in);
+            throw;
+        }
+        std::swap(ctx->stream, ctx->wm_stream);
+    }
+    (void)hipEventDestroy(ev_in);
     {
         const size_t len[6] = {nv, nv, N - 1, nv - ni, ni, 4};
         const Fr *src[6] = {uvw[0].as<Fr>(), uvw[1].as<Fr>(), L.as<Fr>(), lg.as<Fr>() + ni, lg.as<Fr>(), d_s.as<Fr>()};
@@ -215,26 +244,13 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
         fetch(os[4], ni, out.gamma_abc_g1, nullptr);
         fetch(os[5], 4, o1, nullptr);
     }
-    {
-        const size_t len[2] = {nv, 4};
-        const Fr *src[2] = {uvw[1].as<Fr>(), d_s.as<Fr>()};
-        const size_t start[3] = {0, nv, nv + 4};
-        canon.ensure((nv + 4) * sizeof(Fr));
-        for (int k = 0; k < 2; k++) fr_from_mont_run(ctx, src[k], canon.as<Fr>() + start[k], len[k]);
-        pts.ensure((res ? 4 : nv + 4) * sizeof(G2Affine));
-        G2Affine *sat = pts.as<G2Affine>();
-        G2AffineU *ou[2] = {res ? res->b2.as<G2AffineU>() : nullptr, nullptr};
-        G2Affine *os[2] = {res ? nullptr : sat, res ? sat : sat + nv};
-        fixed_base_g2_multi(ctx, g2, canon.as<Fr>(), nv + 4, 2, start, ou, os);
-        if (!res) {
-            ZK_HIP(hipMemcpyAsync(out.b_g2_query, os[0], nv * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
-            const G2Affine *o = reinterpret_cast<const G2Affine *>(out.b_g2_query);
-            for (size_t i = 0; i < nv; i++) out.b_g2_inf[i] = o[i].is_inf() ? 1 : 0;
-        }
-        ZK_HIP(hipMemcpyAsync(o2, os[1], 4 * sizeof(G2Affine), hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->wm_stream));               // the G2 pass
+    if (!res) {
+        ZK_HIP(hipMemcpy(out.b_g2_query, g2_sat[0], nv * sizeof(G2Affine), hipMemcpyDeviceToHost));
+        const G2Affine *o = reinterpret_cast<const G2Affine *>(out.b_g2_query);
+        for (size_t i = 0; i < nv; i++) out.b_g2_inf[i] = o[i].is_inf() ? 1 : 0;
     }
+    ZK_HIP(hipMemcpy(o2, g2_sat[1], 4 * sizeof(G2Affine), hipMemcpyDeviceToHost));
     if (res) {
         memcpy(&res->alpha_g1, o1, 96); memcpy(&res->beta_g1, o1 + 12, 96); memcpy(&res->delta_g1, o1 + 24, 96);
         memcpy(&res->beta_g2, o2 + 24, 192); memcpy(&res->delta_g2, o2 + 48, 192);
