@@ -160,6 +160,7 @@ struct zkg16_ctx {
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
     int num_cus = 256;
+    bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
     zk::FixedBaseCache fb_g1, fb_g2;
 };
 

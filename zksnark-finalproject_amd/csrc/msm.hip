@@ -630,7 +630,7 @@ static void msm_launch_fixups(zkg16_ctx *ctx, MsmSlot &slot, hipStream_t fs) {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_fixup_g2" : "msm_fixup_g1", (double)slot.acc_grid * 64, fs);
         hipLaunchKernelGGL(msm_fixup_kernel<F>, dim3(slot.acc_grid), dim3(64), 0, fs, a, q);
     }
-    static bool lds_attr_set = false;     // one flag per instantiation (G1 / G2): 256 * 448 B > the 64 KiB default for G2
+    bool &lds_attr_set = ctx->lds_attr_fixup[FieldTraits<F>::g2 ? 1 : 0];     // per ctx (= per device): 256 * 448 B > the 64 KiB default for G2
     if (!lds_attr_set) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_long_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fixup_fold_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -363,7 +363,7 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
 
 // In-place from the caller's view: the result ends in `data`; `tmp` (N elements) is scratch.
 void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset) {
-    static bool lds_attr_set = false;
+    bool &lds_attr_set = ctx->lds_attr_ntt;          // per ctx (= per device)
     if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles: above the 64 KiB default dynamic-LDS cap
         for (const void *f : {reinterpret_cast<const void *>(ntt_pass_cols), reinterpret_cast<const void *>(ntt_pass_rows),
                               reinterpret_cast<const void *>(ntt_pass_cols_u), reinterpret_cast<const void *>(ntt_pass_rows_u)})
