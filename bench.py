@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--synthetic-rows", action="store_true", help="shape-exact synthetic rows instead of the synthesized MatrixCircuit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: several ranks on one GPU)")
-    ap.add_argument("--cpu-sample-n", type=int, default=12, help="matrix size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample-n", type=int, default=16, help="matrix size of the bounded CPU-baseline sample")
     ap.add_argument("--parallel", default="shard", choices=["shard", "replicas"],
                     help="N > 1: shard = one proof's index ranges over the ranks (north_star; strong scaling); "
                          "replicas = every rank proves its own proofs on the whole key (no exchange; weak scaling)")
@@ -94,7 +94,7 @@ def make_key(dev, r1cs, shp, seed):
     return pk
 
 
-def cpu_baseline(sample_n, target_nc, threads):
+def cpu_baseline(sample_n, target_nc, threads, dev=None):
     """Times the CPU oracle (port of the arkworks algorithms; oracle/) on a bounded sample of the same workload
     family and scales by constraint count to the metric's unit (proofs/s of the target circuit)."""
     sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
@@ -109,7 +109,9 @@ def cpu_baseline(sample_n, target_nc, threads):
     r1cs, z = circ.r1cs, circ.z
     shp = dict(nc=circ.num_constraints, num_vars=circ.num_vars, domain=circ.domain)
     rng = random.Random(7)
-    pk, _ = synth.make_pk(orc, r1cs, shp["num_vars"], rng)
+    # the sample's key: points from the device's fixed-base kernel when a device is at hand (untimed; the timed part is the
+    # CPU prover alone)
+    pk, _ = synth.make_pk(orc, r1cs, shp["num_vars"], rng, point_gen=dev.fixed_base if dev is not None else None)
     used = orc.set_threads(threads)
     t0 = time.time()
     orc.prove(pk, fr_mont(12345), fr_mont(67890), r1cs, z)
@@ -299,7 +301,7 @@ def main():
         if in_flight:
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, shp["nc"], min(os.cpu_count() or 1, 16))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, shp["nc"], min(os.cpu_count() or 1, 16), dev)
         print(json.dumps(out), flush=True)
     dev.close()
     if world > 1:
