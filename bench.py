@@ -117,7 +117,17 @@ def cpu_baseline(sample_n, target_nc, threads, dev=None):
     orc.prove(pk, fr_mont(12345), fr_mont(67890), r1cs, z)
     dt = time.time() - t0
     cps = shp["nc"] / dt
+    # the same prover on one thread (the published curve looks single-threaded), on a quarter-size sample
+    small = matrix_circuit(np.ones((sample_n // 2, sample_n // 2), dtype=np.uint64), np.ones((sample_n // 2, sample_n // 2), dtype=np.uint64))
+    pk1, _ = synth.make_pk(orc, small.r1cs, small.num_vars, rng, point_gen=dev.fixed_base if dev is not None else None)
+    orc.set_threads(1)
+    t1 = time.time()
+    orc.prove(pk1, fr_mont(12345), fr_mont(67890), small.r1cs, small.z)
+    dt1 = time.time() - t1
+    orc.set_threads(threads)
     return dict(value=cps / target_nc, unit="proofs/s", cores=used, kind="port",
+                one_thread={"value": small.num_constraints / dt1 / target_nc, "unit": "proofs/s", "cores": 1,
+                            "sample": "n=%d (%d constraints) in %.2f s" % (sample_n // 2, small.num_constraints, dt1)},
                 sample="oracle prove of the same MatrixCircuit at n=%d (%d constraints, domain 2^%d) in %.2f s on %d threads "
                        "(OpenMP: one task per MSM window, as ark's `parallel` feature); scaled by constraint count to n=32-equivalent proofs/s"
                        % (sample_n, shp["nc"], shp["domain"].bit_length() - 1, dt, used),
