@@ -278,6 +278,24 @@ def test_prove_random_vs_oracle_and_exponent(dev, oracle):
         f(hnd)
 
 
+@pytest.mark.parametrize("nc,ni,nv,r,s", [(1, 1, 2, 5, 7), (2, 2, 3, 0, 9), (5, 1, 4, 11, 0), (17, 3, 9, 0, 0), (64, 4, 40, 1, 1),
+                                          (300, 2, 1000, P.R_MOD - 1, 2), (1000, 5, 130, 3, P.R_MOD - 1)])
+def test_prove_edge_shapes_vs_oracle(dev, oracle, nc, ni, nv, r, s):
+    """Degenerate shapes through the whole path: a single constraint, one instance variable (no public input), more
+    variables than constraints and the reverse, r and/or s equal to 0, 1, r - 1 (ark-groth16 skips the B1 MSM when r = 0:
+    the group element is the same)."""
+    rng = random.Random(1000 * nc + nv)
+    A, B, C, z = synth.random_r1cs(rng, nc, ni, nv)
+    r1cs = synth.r1cs_arrays(A, B, C, ni)
+    pk, _ = synth.make_pk(oracle, r1cs, nv, rng, point_gen=dev.fixed_base)
+    zm = fr_mont_vec(z)
+    ph = dev.pk_load(pk, ni)
+    proof, inf = dev.prove(ph, fr_mont(r), fr_mont(s), r1cs, zm)
+    dev.pk_free(ph)
+    eproof, einf = oracle.prove(pk, fr_mont(r), fr_mont(s), r1cs, zm)
+    assert np.array_equal(inf, einf) and np.array_equal(proof, eproof)
+
+
 def test_error_paths(dev):
     from zksnark_finalproject_amd import Zkg16Error
     with pytest.raises(Zkg16Error) as e:
