@@ -296,6 +296,24 @@ def test_prove_edge_shapes_vs_oracle(dev, oracle, nc, ni, nv, r, s):
     assert np.array_equal(inf, einf) and np.array_equal(proof, eproof)
 
 
+@pytest.mark.parametrize("n", [32, 46, 128])
+def test_full_size_request_verifies(dev, n):
+    """BASELINE.json's sizes end to end with a size-independent check: the reference's MatrixCircuit at 32x32 (472,564
+    constraints, domain 2^19), 46x46 (domain 2^20) and 128x128 (domain 2^24), synthesized -> device setup -> device proof -> host pairing
+    verification == true (the reference's own acceptance test, constraints.rs:231-272), and false for another public input."""
+    from zksnark_finalproject_amd import handlers
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 1 << 32, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 32, size=(n, n), dtype=np.uint64)
+    res = handlers.prove_matrix(dev, n, a, b, seed=n)
+    circ = res["_circuit"]
+    assert circ.domain == {32: 1 << 19, 46: 1 << 20, 128: 1 << 24}[n]      # 128: 10.7 M constraints, the three-pass NTT
+    assert handlers.verify_proof(res["vk"], circ.public_inputs, res["proof"])["valid"] is True
+    bad = circ.public_inputs.copy()
+    bad[2] = bad[0]                     # claim hash_c = hash_a
+    assert handlers.verify_proof(res["vk"], bad, res["proof"])["valid"] is False
+
+
 def test_error_paths(dev):
     from zksnark_finalproject_amd import Zkg16Error
     with pytest.raises(Zkg16Error) as e:
