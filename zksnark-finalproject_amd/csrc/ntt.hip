@@ -307,16 +307,23 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) 
     }
 }
 
-// out[i] = scale * base^i
+// out[i] = scale * base^i: a thread raises base to its first index (square-and-multiply) and walks FR_POWERS_RUN
+// consecutive powers from there (one product each) instead of exponentiating for every element
+static constexpr int FR_POWERS_RUN = 8;
 __global__ void fr_powers_kernel(Fr *out, Fr base, Fr scale, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    gst(out + i, fp_mul(fp_pow_u64(base, (uint64_t)i), scale));
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * FR_POWERS_RUN;
+    if (i0 >= n) return;
+    Fr cur = fp_mul(fp_pow_u64(base, (uint64_t)i0), scale);
+    for (int k = 0; k < FR_POWERS_RUN && i0 + k < n; k++) {
+        gst(out + i0 + k, cur);
+        cur = fp_mul(cur, base);
+    }
 }
+static unsigned fr_powers_grid(size_t n) { return (unsigned)(((n + FR_POWERS_RUN - 1) / FR_POWERS_RUN + 255) / 256); }
 
 void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n) {
     if (!n) return;
-    hipLaunchKernelGGL(fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, base, scale, n);
+    hipLaunchKernelGGL(fr_powers_kernel, dim3(fr_powers_grid(n)), dim3(256), 0, ctx->stream, out, base, scale, n);
     ZK_HIP(hipGetLastError());
 }
 
@@ -351,7 +358,7 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
     t->g.alloc(n * sizeof(Fr));
     t->gi.alloc(n * sizeof(Fr));
     const int bs = 256;
-    const unsigned grid = (unsigned)((n + bs - 1) / bs);
+    const unsigned grid = fr_powers_grid(n);
     hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->w.as<Fr>(), root, Fr::one(), n);
     hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->g.as<Fr>(), g, Fr::one(), n);
     hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->gi.as<Fr>(), g_inv, t->n_inv, n);
