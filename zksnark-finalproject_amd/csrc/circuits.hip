@@ -480,9 +480,10 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     Circuit &seg_a = c->add_segment(2 * nn);
     Circuit &seg_b = c->add_segment(2 * nn + hw);
     Circuit &seg_mid = c->add_segment(0);
-    Circuit &seg_c = c->add_segment(2 * nn + 2 * hw);
+    Circuit &seg_c = c->add_segment(2 * nn + 2 * hw);           // matrix_mul
+    Circuit &seg_d = c->add_segment(2 * nn + 2 * hw + nn + nn * (n + 1));      // hash of the product: starts after matrix_mul's witnesses
     Circuit &seg_tail = c->add_segment(0);
-    std::exception_ptr err_a, err_b, err_c;
+    std::exception_ptr err_a, err_b, err_c, err_d;
     auto build_a = [&]() {
         try {
             hash_a = poseidon_hash_native(av.data(), nn);
@@ -495,43 +496,59 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
             hb = poseidon_hash_gadget(seg_b, mb);
         } catch (...) { err_b = std::current_exception(); g_terms = true; }
     };
+    // hash of C: entry (i, j) of the product is the symbolic sum  sum_ij + sum_k product_ijk  (constraints.rs:87-92), whose
+    // variables matrix_mul allocates in a fixed order — [n*n pre-allocated entries][per (i, j): sum, then n products] — so the
+    // linear combinations can be written down without waiting for matrix_mul to run
+    auto build_d = [&]() {
+        try {
+            hash_c = poseidon_hash_native(cv.data(), nn);
+            std::vector<Lc> mc(nn);
+            const Fr one = Fr::one();
+            for (size_t e = 0; e < nn; e++) {
+                const size_t first = seg_c.wit_base + nn + e * (n + 1);
+                mc[e].t.reserve(n + 1);
+                for (size_t k = 0; k <= n; k++) mc[e].t.push_back(Term{WIT | (VarId)(first + k), one});
+                mc[e].val = cv[e];
+                mc[e].is_const = false;
+            }
+            hc = poseidon_hash_gadget(seg_d, mc);
+        } catch (...) { err_d = std::current_exception(); g_terms = true; }
+    };
     // the inputs come first in arkworks' order, but their values (the native hashes) are only needed at the end: the
     // instance slots are reserved now and filled after the builders have produced them
     Lc in_a = head.new_input(Fr::zero()), in_b = head.new_input(Fr::zero());
     for (size_t i = 0; i < nn; i++) ma[i] = head.new_witness(av[i]);
     for (size_t i = 0; i < nn; i++) mb[i] = head.new_witness(bv[i]);
-    std::thread ta, tb;
+    std::thread ta, tb, td;
     if (threaded) {
         ta = std::thread(build_a);
         tb = std::thread(build_b);
+        td = std::thread(build_d);
     } else {            // one after another: every segment starts where the previous one actually ended
         build_a();
         seg_b.wit_base = seg_a.next_wit();
         build_b();
         seg_c.wit_base = seg_b.next_wit();
+        seg_d.wit_base = seg_c.wit_base + nn + nn * (n + 1);
     }
-    // matrix_mul (constraints.rs:78-99) + the hash of the product, on this thread
+    // matrix_mul (constraints.rs:78-99), on this thread
     try {
-        hash_c = poseidon_hash_native(cv.data(), nn);
-        std::vector<Lc> mc(nn);
-        for (size_t i = 0; i < nn; i++) mc[i] = seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
+        for (size_t i = 0; i < nn; i++) seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
         for (size_t i = 0; i < n; i++)
             for (size_t j = 0; j < n; j++) {
-                Lc sum = seg_c.new_witness(Fr::zero());
+                seg_c.new_witness(Fr::zero());                  // the sum's seed (:87); the running sum itself is symbolic
                 for (size_t k = 0; k < n; k++) {
                     const Lc &ij = ma[i * n + k], &jk = mb[k * n + j];
                     Lc product = seg_c.mul(ij, jk);            // `*`: product witness + constraint (:91)
-                    sum = Circuit::add(sum, product);          // symbolic (:92)
                     seg_c.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
                 }
-                mc[i * n + j] = sum;
             }
-        hc = poseidon_hash_gadget(seg_c, mc);
     } catch (...) { err_c = std::current_exception(); g_terms = true; }
-    if (threaded) { ta.join(); tb.join(); }
-    for (const std::exception_ptr &e : {err_a, err_b, err_c})
+    if (threaded) { ta.join(); tb.join(); td.join(); }
+    else build_d();
+    for (const std::exception_ptr &e : {err_a, err_b, err_c, err_d})
         if (e) std::rethrow_exception(e);
-    if (seg_b.wit_base != seg_a.next_wit() || seg_c.wit_base != seg_b.next_wit()) throw std::logic_error("matrix circuit: segment offsets do not line up");
+    if (seg_b.wit_base != seg_a.next_wit() || seg_c.wit_base != seg_b.next_wit() || seg_d.wit_base != seg_c.next_wit()) throw std::logic_error("matrix circuit: segment offsets do not line up");
     head.instance[1] = hash_a;
     head.instance[2] = hash_b;
     in_a.val = hash_a;
