@@ -532,7 +532,7 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "ntt_mode")) {
-        if (value < 0 || value > 1) return ZKG16_ERR_BAD_ARG;
+        if (value != 0 && value != 1 && value != 3) return ZKG16_ERR_BAD_ARG;      // 3: unsaturated, but three passes above 2^22
         ctx->opt_ntt_mode = (int)value;
         return ZKG16_OK;
     }

@@ -78,6 +78,7 @@ struct PendingEvent;
 struct NttTables {          // per domain size, built on device on first use
     int log_n = 0;
     DevBuf w;               // w[j]  = omega_N^j,            j < N
+    DevBuf wu;              // the same in the unsaturated form (36 B per entry); only built for N > 2^22
     DevBuf g;               // g[i]  = 7^i                   (coset fft pre-multiply)
     DevBuf gi;              // gi[i] = 7^-i * N^-1           (coset ifft post-multiply)
     Fr n_inv;               // N^-1 (plain ifft post-multiply)

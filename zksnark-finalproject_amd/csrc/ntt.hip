@@ -58,6 +58,7 @@ struct NttPassArgs {
     const Fr *in;
     Fr *out;
     const Fr *w;       // w_N^j table
+    const uint32_t *wu; // the same table in the unsaturated form (9 x u32 per entry), only for the global-twiddle kernels
     const Fr *pre;     // optional per-input-index multiplier (coset fft), else null
     const Fr *post;    // optional per-output-index multiplier (coset ifft), else null
     Fr post_const;     // used when post_const_on (plain ifft: N^-1)
@@ -202,25 +203,43 @@ __device__ __forceinline__ void lds_st_u(uint32_t *s, int stride, int e, const F
     for (int k = 0; k < 9; k++) s[k * stride + p] = v.l[k];
 }
 
-__device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride) {
+// TL = log2 of the tile (11: twiddles of the sub-transform staged in LDS; 12: the tile fills the LDS, twiddles come from a
+// U-form table in global memory — used above 2^22, where it makes the transform two passes instead of three)
+template <int TL, bool GTW>
+__device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride, const NttPassArgs &a) {
+    constexpr int TILE = 1 << TL;
     const int tid = threadIdx.x;
+    const unsigned nmask = (1u << a.log_n) - 1u;
     for (int s = log_m - 1; s >= 0; s--) {
         const int h = 1 << s;
-        for (int u = tid; u < NTT_TILE / 2; u += NTT_THREADS_U) {
+        for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
             const int c = u >> (log_m - 1);
             const int v = u & ((1 << (log_m - 1)) - 1);
             const int j = v & (h - 1);
             const int blk = v >> s;
             const int i0 = (c << log_m) + (blk << (s + 1)) + j;
             const int i1 = i0 + h;
-            const FrU a = lds_ld_u(s_data, NTT_TILE, i0);
-            const FrU b = lds_ld_u(s_data, NTT_TILE, i1);
-            const FrU sum = fru_cond_sub<true>(fru_add(a, b));
-            FrU dif = fru_sub_2r(a, b);
-            if (s > 0) dif = fru_mul(dif, lds_ld_u(s_tw, tw_stride, j << (log_m - 1 - s)));
-            else dif = fru_cond_sub<true>(dif);       // the last stage's twiddle is w^0 = 1
-            lds_st_u(s_data, NTT_TILE, i0, sum);
-            lds_st_u(s_data, NTT_TILE, i1, dif);
+            const FrU x = lds_ld_u(s_data, TILE, i0);
+            const FrU y = lds_ld_u(s_data, TILE, i1);
+            const FrU sum = fru_cond_sub<true>(fru_add(x, y));
+            FrU dif = fru_sub_2r(x, y);
+            if (s > 0) {
+                FrU tw;
+                if (GTW) {
+                    unsigned idx = (unsigned)(j << (log_m - 1 - s)) << (a.log_n - log_m);
+                    if (a.inverse) idx = ((1u << a.log_n) - idx) & nmask;
+                    const uint32_t *t = a.wu + (size_t)idx * 9;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) tw.l[k] = t[k];
+                } else {
+                    tw = lds_ld_u(s_tw, tw_stride, j << (log_m - 1 - s));
+                }
+                dif = fru_mul(dif, tw);
+            } else {
+                dif = fru_cond_sub<true>(dif);       // the last stage's twiddle is w^0 = 1
+            }
+            lds_st_u(s_data, TILE, i0, sum);
+            lds_st_u(s_data, TILE, i1, dif);
         }
         __syncthreads();
     }
@@ -243,12 +262,14 @@ __device__ __forceinline__ FrU load_u(const Fr *in, const Fr *pre, size_t gi) {
     return fru_mul(x, fru_c266());
 }
 
+template <int TL, bool GTW>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) {
+    constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *s_data = smem;                         // [9][TILE]
-    uint32_t *s_tw = smem + 9 * NTT_TILE;            // [9][tw_stride]
+    uint32_t *s_tw = smem + 9 * TILE;                // [9][tw_stride] (not with global twiddles)
     const int tw_stride = 1 << (a.log_n1 - 1);
-    const int log_c = NTT_TILE_LOG - a.log_n1;
+    const int log_c = TL - a.log_n1;
     const int C = 1 << log_c;
     const unsigned nmask = (1u << a.log_n) - 1u;
     const size_t n2 = (size_t)1 << a.log_n2;
@@ -256,17 +277,17 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
     Fr *out = a.out + (size_t)blockIdx.y * a.batch_stride;
 
-    stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n1, a.inverse);
-    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+    if (!GTW) stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n1, a.inverse);
+    for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int c = t & (C - 1), i1 = t >> log_c;
         const size_t gi = (size_t)i1 * n2 + col0 + c;
-        lds_st_u(s_data, NTT_TILE, (c << a.log_n1) + i1, load_u(in, a.pre, gi));
+        lds_st_u(s_data, TILE, (c << a.log_n1) + i1, load_u(in, a.pre, gi));
     }
     __syncthreads();
-    lds_dif_u(s_data, s_tw, a.log_n1, tw_stride);
-    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+    lds_dif_u<TL, GTW>(s_data, s_tw, a.log_n1, tw_stride, a);
+    for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int c = t & (C - 1), k1 = t >> log_c;
-        const FrU v = lds_ld_u(s_data, NTT_TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
+        const FrU v = lds_ld_u(s_data, TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
         const size_t i2 = col0 + c;
         unsigned e = (unsigned)(((i2 * (size_t)k1) << a.tw_shift) & nmask);    // inter-pass twiddle w_M^(i2*k1), w_M = w_N^(2^tw_shift)
         if (a.inverse) e = ((1u << a.log_n) - e) & nmask;
@@ -274,37 +295,48 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     }
 }
 
+template <int TL, bool GTW>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) {
+    constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *s_data = smem;
-    uint32_t *s_tw = smem + 9 * NTT_TILE;
+    uint32_t *s_tw = smem + 9 * TILE;
     const int tw_stride = a.log_n2 > 0 ? 1 << (a.log_n2 - 1) : 1;
-    const int log_r = NTT_TILE_LOG - a.log_n2;
+    const int log_r = TL - a.log_n2;
     const int R = 1 << log_r;
     const size_t n1 = (size_t)1 << a.log_n1;
     const size_t n2 = (size_t)1 << a.log_n2;
     const size_t row0 = (size_t)blockIdx.x * R;
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
 
-    stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
-    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+    if (!GTW) stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
+    for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int i2 = t & ((1 << a.log_n2) - 1), r = t >> a.log_n2;
         FrU v;
 #pragma unroll
         for (int k = 0; k < 9; k++) v.l[k] = 0;
         if (row0 + r < n1) v = load_u(in, a.pre, (row0 + r) * n2 + i2);
-        lds_st_u(s_data, NTT_TILE, t, v);
+        lds_st_u(s_data, TILE, t, v);
     }
     __syncthreads();
-    lds_dif_u(s_data, s_tw, a.log_n2, tw_stride);
+    lds_dif_u<TL, GTW>(s_data, s_tw, a.log_n2, tw_stride, a);
     const FrU post_c = a.post_const_on ? fru_repack(a.post_const) : fru_one_sat();
-    for (int t = threadIdx.x; t < NTT_TILE; t += NTT_THREADS_U) {
+    for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int r = t & (R - 1), k2 = t >> log_r;
         if (row0 + r >= n1) continue;
-        const FrU v = lds_ld_u(s_data, NTT_TILE, (r << a.log_n2) + bitrev(k2, a.log_n2));
+        const FrU v = lds_ld_u(s_data, TILE, (r << a.log_n2) + bitrev(k2, a.log_n2));
         const size_t k = (size_t)blockIdx.y + (((row0 + r) + n1 * (size_t)k2) << a.out_stride_log);
         gst(a.out + k, fru_mul_to_sat(v, a.post ? fru_repack(gld(a.post + k)) : post_c));
     }
+}
+
+// U-form copy of the w table (9 x u32 per entry) for the global-twiddle kernels
+__global__ void __launch_bounds__(256) ntt_wu_kernel(const Fr *w, uint32_t *wu, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FrU u = fru_from_sat(gld(w + i));
+#pragma unroll
+    for (int k = 0; k < 9; k++) wu[i * 9 + k] = u.l[k];
 }
 
 // out[i] = scale * base^i: a thread raises base to its first index (square-and-multiply) and walks FR_POWERS_RUN
@@ -371,15 +403,16 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
 // In-place from the caller's view: the result ends in `data`; `tmp` (N elements) is scratch.
 void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset) {
     bool &lds_attr_set = ctx->lds_attr_ntt;          // per ctx (= per device)
-    if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles: above the 64 KiB default dynamic-LDS cap
+    if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles, or a 144 KiB tile: above the 64 KiB default dynamic-LDS cap
         for (const void *f : {reinterpret_cast<const void *>(ntt_pass_cols), reinterpret_cast<const void *>(ntt_pass_rows),
-                              reinterpret_cast<const void *>(ntt_pass_cols_u), reinterpret_cast<const void *>(ntt_pass_rows_u)})
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true>)})
             ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     const bool uform = ctx->opt_ntt_mode != 0;          // 1 (default): unsaturated butterflies; 0: saturated (the first version)
-    auto *k_cols = uform ? ntt_pass_cols_u : ntt_pass_cols;
-    auto *k_rows = uform ? ntt_pass_rows_u : ntt_pass_rows;
+    auto *k_cols = uform ? ntt_pass_cols_u<11, false> : ntt_pass_cols;
+    auto *k_rows = uform ? ntt_pass_rows_u<11, false> : ntt_pass_rows;
     const unsigned nthreads = uform ? NTT_THREADS_U : NTT_THREADS;
     if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
@@ -395,7 +428,37 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
     a.post_const = t->n_inv;
     auto lds_bytes = [uform](int log_m) { return (size_t)(uform ? 9 : 8) * 4 * (NTT_TILE + (log_m > 0 ? (1 << (log_m - 1)) : 1)); };
 
-    if (log_n <= NTT_MAX_SUB_LOG) {
+    if (uform && ctx->opt_ntt_mode != 3 && log_n > 2 * NTT_MAX_SUB_LOG && log_n <= 24) {
+        // 2^23, 2^24: two passes over 4096-point tiles (N1 = 2^(log_n - 12) columns-first, N2 = 2^12) with the sub-transform
+        // twiddles read from a U-form table in global memory, instead of three passes over 2048-point tiles
+        if (!t->wu.p) {
+            t->wu.alloc(n * 9 * sizeof(uint32_t));
+            hipLaunchKernelGGL(ntt_wu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->w.as<Fr>(), t->wu.as<uint32_t>(), n);
+            ZK_HIP(hipGetLastError());
+        }
+        a.wu = t->wu.as<uint32_t>();
+        a.log_n2 = 12;
+        a.log_n1 = log_n - 12;
+        const size_t big_lds = (size_t)9 * 4 * 4096;
+        {
+            NttPassArgs p1 = a;
+            p1.in = data; p1.out = data;
+            p1.pre = pre;
+            p1.batch_stride = 0;
+            const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (12 - a.log_n1));
+            ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
+            hipLaunchKernelGGL((ntt_pass_cols_u<12, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+        }
+        {
+            NttPassArgs p2 = a;
+            p2.in = data; p2.out = tmp;
+            p2.post = post;
+            p2.post_const_on = post_const_on;
+            const unsigned grid = (unsigned)((size_t)1 << a.log_n1);
+            ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
+            hipLaunchKernelGGL((ntt_pass_rows_u<12, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+        }
+    } else if (log_n <= NTT_MAX_SUB_LOG) {
         a.log_n1 = 0;
         a.log_n2 = log_n;
         a.in = data;
