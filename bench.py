@@ -308,6 +308,18 @@ def main():
         out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": 6.75, "unit": "G mixed additions/s", "frac": gadd / 6.75,
                       "note": "entries = one per window for every scalar other than 0 and 1 (B1's density filter not counted: slight "
                               "over-estimate); peak = the XYZZ mixed addition alone in a register-resident loop at the kernel's occupancy"}
+        # second kernel family of the path: one transform of the workload's domain, timed alone after the timed region
+        # (64 algorithmic bytes per element: each element read once and written once)
+        try:
+            log_n = shp["domain"].bit_length() - 1
+            dev.bench_ntt(log_n, 1, 1, 2)
+            ntt_ms = dev.bench_ntt(log_n, 1, 1, 10)
+            out["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_cols_u + ntt_pass_rows_u (one coset-inverse transform of 2^%d)" % log_n,
+                                   "achieved": 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9 / 8000.0, "ms": ntt_ms, "transforms_per_proof": 7,
+                                   "note": "integer-ALU bound too: ~7 Fr products per element per pass, two passes"}
+        except Exception as e:      # noqa: BLE001 - the extra leg must never cost the contract line
+            out["roofline_ntt"] = {"error": repr(e)}
         if in_flight:
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
