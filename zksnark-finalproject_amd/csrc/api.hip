@@ -5,6 +5,7 @@
 //
 // There is NO CPU fallback: without a HIP device zkg16_init fails with ZKG16_ERR_NO_DEVICE.
 #include <chrono>
+#include <functional>
 
 #include "common.hpp"
 
@@ -220,7 +221,8 @@ double now_ms() {
 }
 
 // The device part of a proof: witness map + the five MSMs over this ctx's pk shard.
-void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const Fr &r, const Fr &s, Partials &out) {
+void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const Fr &r, const Fr &s, Partials &out,
+                  const std::function<void()> *before_witness_map = nullptr) {
     const size_t m_total = rc.num_variables;
     if (wit.n != m_total || pk.m_total != m_total) throw HipError{hipErrorInvalidValue, "prove: assignment / key length mismatch", __FILE__, __LINE__};
     const size_t N = (size_t)1 << rc.log_n;
@@ -280,6 +282,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     const bool wm_concurrent = ctx->opt_wm_concurrent != 0;
     if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);      // every launch helper targets ctx->stream
     try {
+        // zkg16_prove (host pointers): the matrices are uploaded here, on the witness map's stream, while the z-side
+        // accumulations queued above already keep the device busy
+        if (before_witness_map) (*before_witness_map)();
         ZK_HIP(hipEventRecord(ev[2], ctx->stream));
         Fr *h = nullptr;
         witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
@@ -380,9 +385,10 @@ Fr fr_from_abi(const uint64_t *l) {
     return v;
 }
 
-int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3],
-              size_t num_instance, size_t num_constraints, size_t num_variables, uint64_t *handle) {
-    if (!handle || num_instance == 0) return ZKG16_ERR_BAD_ARG;
+// validate + allocate (nothing is copied yet)
+int r1cs_create(const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3], size_t num_instance,
+                size_t num_constraints, size_t num_variables, std::unique_ptr<R1csDev> &out) {
+    if (num_instance == 0) return ZKG16_ERR_BAD_ARG;
     for (int i = 0; i < 3; i++)
         if (!rp[i] || (rp[i][num_constraints] && (!col[i] || !cf[i]))) return ZKG16_ERR_BAD_ARG;
     const size_t dom = num_constraints + num_instance;
@@ -397,18 +403,34 @@ int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const
     r->log_n = log_n;
     for (int i = 0; i < 3; i++) {
         const size_t nnz = rp[i][num_constraints];
-        for (size_t k = 0; k < nnz; k++)
-            if (col[i][k] >= num_variables) return ZKG16_ERR_BAD_ARG;
+        uint32_t top = 0;
+        for (size_t k = 0; k < nnz; k++) top = col[i][k] > top ? col[i][k] : top;
+        if (nnz && top >= num_variables) return ZKG16_ERR_BAD_ARG;
         r->nnz[i] = nnz;
         r->rp[i].alloc((num_constraints + 1) * sizeof(uint64_t));
         r->col[i].alloc(nnz * sizeof(uint32_t));
         r->cf[i].alloc(nnz * sizeof(Fr));
-        ZK_HIP(hipMemcpyAsync(r->rp[i].p, rp[i], (num_constraints + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        if (nnz) {
-            ZK_HIP(hipMemcpyAsync(r->col[i].p, col[i], nnz * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            ZK_HIP(hipMemcpyAsync(r->cf[i].p, cf[i], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    }
+    out = std::move(r);
+    return ZKG16_OK;
+}
+// host -> device copies of the three matrices, queued on ctx->stream (pageable source: the call itself may take a while)
+void r1cs_copy(zkg16_ctx *ctx, R1csDev &r, const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3]) {
+    for (int i = 0; i < 3; i++) {
+        ZK_HIP(hipMemcpyAsync(r.rp[i].p, rp[i], (r.num_constraints + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        if (r.nnz[i]) {
+            ZK_HIP(hipMemcpyAsync(r.col[i].p, col[i], r.nnz[i] * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            ZK_HIP(hipMemcpyAsync(r.cf[i].p, cf[i], r.nnz[i] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         }
     }
+}
+int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3],
+              size_t num_instance, size_t num_constraints, size_t num_variables, uint64_t *handle) {
+    if (!handle) return ZKG16_ERR_BAD_ARG;
+    std::unique_ptr<R1csDev> r;
+    const int rc = r1cs_create(rp, col, cf, num_instance, num_constraints, num_variables, r);
+    if (rc) return rc;
+    r1cs_copy(ctx, *r, rp, col, cf);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     *handle = ctx->next_handle++;
     ctx->r1cs[*handle] = std::move(r);
@@ -751,15 +773,33 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
                 const uint64_t *c_row_ptr, const uint32_t *c_col, const uint64_t *c_coeff,
                 size_t num_instance, size_t num_constraints, const uint64_t *full_assignment, size_t n_assign,
                 uint64_t proof_out[48], uint8_t inf_out[3]) {
-    uint64_t rh = 0, wh = 0;
-    int rc = zkg16_r1cs_load(ctx, a_row_ptr, a_col, a_coeff, b_row_ptr, b_col, b_coeff, c_row_ptr, c_col, c_coeff, num_instance,
-                             num_constraints, n_assign, &rh);
-    if (rc) return rc;
-    rc = zkg16_witness_load(ctx, full_assignment, n_assign, &wh);
-    if (!rc) rc = zkg16_prove_resident(ctx, pk_handle, rh, wh, r, s, proof_out, inf_out);
-    if (wh) zkg16_witness_free(ctx, wh);
-    zkg16_r1cs_free(ctx, rh);
-    return rc;
+    if (!r || !s || !proof_out || !inf_out || !full_assignment || n_assign == 0) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    if (!pk) return ZKG16_ERR_BAD_HANDLE;
+    if (pk->shard_count != 1) return ZKG16_ERR_BAD_ARG;
+    const uint64_t *rp[3] = {a_row_ptr, b_row_ptr, c_row_ptr};
+    const uint32_t *col[3] = {a_col, b_col, c_col};
+    const uint64_t *cf[3] = {a_coeff, b_coeff, c_coeff};
+    std::unique_ptr<R1csDev> rc;
+    const int st = r1cs_create(rp, col, cf, num_instance, num_constraints, n_assign, rc);
+    if (st) return st;
+    if (pk->m_total != n_assign || pk->num_instance != num_instance || pk->n_h_total != ((size_t)1 << rc->log_n) - 1) return ZKG16_ERR_BAD_ARG;
+    // the assignment first (the z-side MSMs need only it); the matrices follow inside prove_device, behind the accumulations
+    WitnessDev wit;
+    wit.n = n_assign;
+    wit.z.alloc(n_assign * sizeof(Fr));
+    ZK_HIP(hipMemcpyAsync(wit.z.p, full_assignment, n_assign * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    const std::function<void()> upload = [&]() { r1cs_copy(ctx, *rc, rp, col, cf); };
+    Partials p;
+    const Fr rr = fr_from_abi(r), ss = fr_from_abi(s);
+    prove_device(ctx, *pk, *rc, wit, rr, ss, p, &upload);
+    const double t0 = now_ms();
+    prove_tail(*pk, rr, ss, p, proof_out, inf_out);
+    ctx->timings[8] = (float)(now_ms() - t0);
+    ctx->timings[9] += ctx->timings[8];
+    ZK_API_END(ctx)
 }
 
 int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12], const uint64_t g2_gen[24],
