@@ -154,6 +154,9 @@ ZKG16_API int zkg16_pairing_check(const uint64_t *g1, const uint8_t *g1_inf, con
  * zkg16_circuit_export yields exactly the arguments of zkg16_r1cs_load / zkg16_witness_load. */
 typedef struct zkg16_circuit zkg16_circuit;
 ZKG16_API int zkg16_circuit_matrix(size_t n, const uint64_t *a /* n*n, row-major */, const uint64_t *b, zkg16_circuit **out);
+/* Only the assignment z (instance || witness, n_assign x 4 limbs) of that circuit for these inputs: the matrices of the
+ * MatrixCircuit depend on n alone, so a caller that kept them from one zkg16_circuit_matrix call needs only this per request. */
+ZKG16_API int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *z, size_t n_assign);
 ZKG16_API int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit **out);
 ZKG16_API void zkg16_circuit_free(zkg16_circuit *c);
 ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]);

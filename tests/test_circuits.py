@@ -139,3 +139,18 @@ def test_segmented_threaded_build_equals_in_order_build(n, monkeypatch):
         for x, y in zip(fast.r1cs[m], plain.r1cs[m]):
             assert np.array_equal(x, y), m
     assert np.array_equal(fast.z, plain.z)
+
+
+@pytest.mark.parametrize("n", [2, 5, 12])
+def test_assignment_only_build_equals_full_synthesis(n):
+    """zkg16_circuit_matrix_witness (term bookkeeping off in every builder thread) gives exactly the assignment of the full
+    synthesis; a wrong variable count is rejected."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit, matrix_witness
+    from zksnark_finalproject_amd import Zkg16Error
+    rng = np.random.default_rng(500 + n)
+    a = rng.integers(0, 1 << 50, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 50, size=(n, n), dtype=np.uint64)
+    c = matrix_circuit(a, b)
+    assert np.array_equal(matrix_witness(a, b, c.num_vars), c.z)
+    with pytest.raises(Zkg16Error):
+        matrix_witness(a, b, c.num_vars + 1)

@@ -296,6 +296,26 @@ def test_prove_edge_shapes_vs_oracle(dev, oracle, nc, ni, nv, r, s):
     assert np.array_equal(inf, einf) and np.array_equal(proof, eproof)
 
 
+def test_request_with_cached_matrices_equals_first_request(dev):
+    """The handler mirror keeps a MatrixCircuit's matrices on the device per size and computes only the assignment for later
+    requests (zkg16_circuit_matrix_witness): same inputs and seed -> byte-identical proof; other inputs -> a valid proof."""
+    from zksnark_finalproject_amd import handlers
+    n = 5
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 1 << 30, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 30, size=(n, n), dtype=np.uint64)
+    dev.__dict__.pop("_matrix_shapes", None)
+    first = handlers.prove_matrix(dev, n, a, b, seed=3)            # synthesizes, exports, uploads, caches
+    assert n in dev._matrix_shapes
+    again = handlers.prove_matrix(dev, n, a, b, seed=3)            # assignment only
+    assert again["proof"] == first["proof"] and again["hash_c"] == first["hash_c"]
+    other = handlers.prove_matrix(dev, n, b, a, seed=4)
+    assert other["hash_c"] != first["hash_c"]
+    assert handlers.verify_proof(other["vk"], other["_circuit"].public_inputs, other["proof"])["valid"] is True
+    full = handlers.prove_matrix(dev, n, b, a, seed=4, keep_key=True)     # the un-cached path
+    assert full["proof"] == other["proof"]
+
+
 @pytest.mark.parametrize("n", [32, 46, 128])
 def test_full_size_request_verifies(dev, n):
     """BASELINE.json's sizes end to end with a size-independent check: the reference's MatrixCircuit at 32x32 (472,564

@@ -45,6 +45,7 @@ SIGNATURES = {
     "zkg16_pairing_check": (C.c_int, [u64p, u8p, u64p, u8p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
     "zkg16_verify": (C.c_int, [u64p, u64p, u64p, u64p, u64p, sz, vp, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),
+    "zkg16_circuit_matrix_witness": (C.c_int, [sz, u64p, u64p, u64p, sz]),
     "zkg16_circuit_fibonacci": (C.c_int, [C.c_uint64, C.c_uint64, sz, C.POINTER(vp)]),
     "zkg16_circuit_free": (None, [vp]),
     "zkg16_circuit_dims": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),

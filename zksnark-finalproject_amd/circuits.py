@@ -48,6 +48,19 @@ def matrix_circuit(a, b):
     return SynthesizedCircuit(h)
 
 
+def matrix_witness(a, b, num_vars):
+    """Only the full assignment of matrix_circuit(a, b) (zkg16_circuit_matrix_witness): for callers that kept the matrices of
+    this size.  num_vars = that circuit's num_instance + num_witness."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    n = a.shape[0]
+    z = np.zeros((num_vars, 4), dtype=np.uint64)
+    rc = _lib.load().zkg16_circuit_matrix_witness(n, a.reshape(-1), b.reshape(-1), z.reshape(-1), num_vars)
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_matrix_witness")
+    return z
+
+
 def fibonacci_circuit(a, b, steps):
     h = C.c_void_p()
     rc = _lib.load().zkg16_circuit_fibonacci(a, b, steps, C.byref(h))

@@ -323,7 +323,7 @@ static void state_signature(const Lc st[3], std::vector<VarId> &ids, std::vector
 }
 
 void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
-    if (!tpls.enabled) { permute_gadget_generic(cs, st); return; }
+    if (!tpls.enabled || !g_terms) { permute_gadget_generic(cs, st); return; }      // !g_terms: assignment-only build
     std::vector<VarId> ids;
     std::vector<uint32_t> shape;
     std::vector<Fr> coeff;
@@ -461,7 +461,7 @@ int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit 
 // [inputs a, b + matrix witnesses] [hash_a gadget] [hash_b gadget] [two equalities] [matrix_mul + hash_c gadget] [input c +
 // equality] — with the hash_a and hash_b segments on their own threads; each segment numbers its witnesses from the offset
 // the earlier ones will have used (poseidon_hash_witnesses).  ZKG16_SYNTH_THREADS=0 builds them one after another.
-static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, const uint64_t *b, bool threaded) {
+static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, const uint64_t *b, bool threaded, bool values_only = false) {
     const size_t nn = n * n;
     std::vector<Fr> av(nn), bv(nn), cv(nn, Fr::zero());
     for (size_t i = 0; i < nn; i++) { av[i] = fr_from_u64(a[i]); bv[i] = fr_from_u64(b[i]); }
@@ -484,16 +484,22 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     Circuit &seg_d = c->add_segment(2 * nn + 2 * hw + nn + nn * (n + 1));      // hash of the product: starts after matrix_mul's witnesses
     Circuit &seg_tail = c->add_segment(0);
     std::exception_ptr err_a, err_b, err_c, err_d;
+    // values_only: only the assignment is wanted (the matrices of this circuit depend on n alone and the caller has them):
+    // every builder runs with the term bookkeeping switched off (g_terms is per thread)
     auto build_a = [&]() {
         try {
+            g_terms = !values_only;
             hash_a = poseidon_hash_native(av.data(), nn);
             ha = poseidon_hash_gadget(seg_a, ma);
+            g_terms = true;
         } catch (...) { err_a = std::current_exception(); g_terms = true; }
     };
     auto build_b = [&]() {
         try {
+            g_terms = !values_only;
             hash_b = poseidon_hash_native(bv.data(), nn);
             hb = poseidon_hash_gadget(seg_b, mb);
+            g_terms = true;
         } catch (...) { err_b = std::current_exception(); g_terms = true; }
     };
     // hash of C: entry (i, j) of the product is the symbolic sum  sum_ij + sum_k product_ijk  (constraints.rs:87-92), whose
@@ -501,6 +507,7 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     // linear combinations can be written down without waiting for matrix_mul to run
     auto build_d = [&]() {
         try {
+            g_terms = !values_only;
             hash_c = poseidon_hash_native(cv.data(), nn);
             std::vector<Lc> mc(nn);
             const Fr one = Fr::one();
@@ -512,6 +519,7 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
                 mc[e].is_const = false;
             }
             hc = poseidon_hash_gadget(seg_d, mc);
+            g_terms = true;
         } catch (...) { err_d = std::current_exception(); g_terms = true; }
     };
     // the inputs come first in arkworks' order, but their values (the native hashes) are only needed at the end: the
@@ -533,6 +541,7 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     }
     // matrix_mul (constraints.rs:78-99), on this thread
     try {
+        g_terms = !values_only;
         for (size_t i = 0; i < nn; i++) seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
         for (size_t i = 0; i < n; i++)
             for (size_t j = 0; j < n; j++) {
@@ -543,6 +552,7 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
                     seg_c.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
                 }
             }
+        g_terms = true;
     } catch (...) { err_c = std::current_exception(); g_terms = true; }
     if (threaded) { ta.join(); tb.join(); td.join(); }
     else build_d();
@@ -553,9 +563,10 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     head.instance[2] = hash_b;
     in_a.val = hash_a;
     in_b.val = hash_b;
+    Lc in_c = head.new_input(hash_c);
+    if (values_only) return;
     seg_mid.enforce_equal(ha, in_a);
     seg_mid.enforce_equal(hb, in_b);
-    Lc in_c = head.new_input(hash_c);
     seg_tail.enforce_equal(hc, in_c);
 }
 
@@ -585,6 +596,30 @@ int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_c
 
 // Releasing a large circuit is ~20 ms of unmapping (160 MB in three arenas at n = 32): it is handed to a detached thread so
 // that the caller's request path does not wait for it.
+// Only the full assignment z = instance || witness of the MatrixCircuit for these inputs (z: (4 + 2 n^2 + ...) x 4 limbs as
+// zkg16_circuit_export would give it; n_assign must equal that circuit's variable count): the R1CS matrices of this circuit
+// depend on n alone, so a server keeps them (and their device copy) per size and asks only for this per request.
+int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *z, size_t n_assign) {
+    if (!a || !b || !z || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
+    zkg16_circuit c;
+    try {
+        const char *env = getenv("ZKG16_SYNTH_THREADS");
+        build_matrix_circuit(&c, n, a, b, !(env && env[0] == '0'), true);
+        const size_t ni = c.head().instance.size();
+        if (ni + c.num_witness() != n_assign) return ZKG16_ERR_BAD_ARG;
+        memcpy(z, c.head().instance.data(), ni * 32);
+        for (const auto &sg : c.segs)
+            if (!sg->witness.empty()) memcpy(z + 4 * (ni + sg->wit_base), sg->witness.data(), sg->witness.size() * 32);
+    } catch (const std::bad_alloc &) {
+        g_terms = true;
+        return ZKG16_ERR_OOM;
+    } catch (const std::exception &) {
+        g_terms = true;
+        return ZKG16_ERR_UNSUPPORTED;
+    }
+    return ZKG16_OK;
+}
+
 void zkg16_circuit_free(zkg16_circuit *c) {
     if (!c) return;
     size_t terms = 0;

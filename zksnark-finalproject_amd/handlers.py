@@ -20,6 +20,26 @@ def _fr_mont(x):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+class _CachedShape:
+    """What a request needs of a MatrixCircuit whose matrices are already on the device: the matrices depend on the size
+    alone, so they are synthesized, exported and uploaded once per size and ctx; a request then only computes its assignment
+    (zkg16_circuit_matrix_witness)."""
+
+    def __init__(self, circ, rh):
+        self.rh = rh
+        self.num_instance, self.num_witness, self.num_vars = circ.num_instance, circ.num_witness, circ.num_vars
+        self.num_constraints, self.domain = circ.num_constraints, circ.domain
+
+    def instantiate(self, a, b):
+        from .circuits import matrix_witness
+        inst = _CachedShape.__new__(_CachedShape)
+        inst.__dict__.update(self.__dict__)
+        inst.z = matrix_witness(a, b, self.num_vars)
+        inst.public_inputs = inst.z[1:self.num_instance].copy()
+        inst.r1cs = None
+        return inst
+
+
 def _setup_and_prove(dev, circ, rng, keep_key=False):
     trap = np.stack([_fr_mont(rng.randrange(1, R_MOD)) for _ in range(5)])
     # arkworks draws random generators; any subgroup generator gives a valid key: [k]G for random k
@@ -27,7 +47,8 @@ def _setup_and_prove(dev, circ, rng, keep_key=False):
     k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
     g1 = scalar_mul("g1", g1_generator(), k)[0]
     g2 = scalar_mul("g2", g2_generator(), k)[0]
-    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    cached = getattr(circ, "rh", None) is not None
+    rh = circ.rh if cached else dev.r1cs_load(circ.r1cs, circ.num_vars)
     t0 = time.perf_counter()
     if keep_key:        # tests want the key on the host as well
         pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)
@@ -41,7 +62,7 @@ def _setup_and_prove(dev, circ, rng, keep_key=False):
     t0 = time.perf_counter()
     proof, inf = dev.prove_resident(ph, rh, wh, r, s)
     proving_time = time.perf_counter() - t0
-    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+    for f, h in ((dev.pk_free, ph), (dev.witness_free, wh)) + (() if cached else ((dev.r1cs_free, rh),)):
         f(h)
     return dict(proof=proof, inf=inf, vk=vk, pk=pk, setup_time=setup_time, proving_time=proving_time, r=r, s=s)
 
@@ -50,7 +71,15 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
     """-> the reference's ProveOutput fields (matrix_proof.rs:80-91)."""
     a = np.asarray(matrix_a, dtype=np.uint64).reshape(size, size)
     b = np.asarray(matrix_b, dtype=np.uint64).reshape(size, size)
-    circ = matrix_circuit(a, b)
+    shapes = dev.__dict__.setdefault("_matrix_shapes", {})
+    if keep_key or size < 2:            # tests want the host copy of everything
+        circ = matrix_circuit(a, b)
+    elif size in shapes:
+        circ = shapes[size].instantiate(a, b)
+    else:
+        full = matrix_circuit(a, b)
+        shapes[size] = _CachedShape(full, dev.r1cs_load(full.r1cs, full.num_vars))
+        circ = shapes[size].instantiate(a, b)
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     ha, hb, hc = circ.public_inputs
     return dict(hash_a=wire.encode_hash(ha), hash_b=wire.encode_hash(hb), hash_c=wire.encode_hash(hc),
