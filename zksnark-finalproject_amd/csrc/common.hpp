@@ -66,7 +66,7 @@ struct DevBuf {
 struct FixedBaseCache {
     // window tables of the two most recently used generators (a request uses the standard generator to derive its own
     // random one, then that one for the whole key) + scratch shared by both
-    struct Entry { std::vector<uint8_t> key; DevBuf table; uint64_t stamp = 0; } e[2];
+    struct Entry { std::vector<uint8_t> key; DevBuf table; uint64_t stamp = 0; int wbits = 0; } e[2];
     uint64_t clock = 0;
     DevBuf sums, pref, win_bases, table_xyzz;
 };

@@ -460,14 +460,16 @@ void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out
 // (Montgomery's trick, one inversion per thread per K points) because an Fq inversion costs more than the 32 mixed adds.
 template <class FU>
 __global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
-fixed_base_table_kernel(const Affine<typename FieldTraits<FU>::Sat> *win_bases /*32*/, XYZZ<FU> *table /*32*255*/) {
+fixed_base_table_kernel(const Affine<typename FieldTraits<FU>::Sat> *win_bases /*nwin*/, XYZZ<FU> *table /*nwin * (2^wbits - 1)*/, int wbits,
+                        int nwin) {
+    const int per = (1 << wbits) - 1;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 32 * 255) return;
-    const int w = id / 255, d = id % 255 + 1;
+    if (id >= nwin * per) return;
+    const int w = id / per, d = id % per + 1;
     const Affine<typename FieldTraits<FU>::Sat> bs = ldv(win_bases + w);
     const Affine<FU> b{to_u(bs.x), to_u(bs.y)};
     XYZZ<FU> acc = XYZZ<FU>::inf();
-    for (int bit = 7; bit >= 0; bit--) {
+    for (int bit = wbits - 1; bit >= 0; bit--) {
         acc = xyzz_dbl(acc);
         if ((d >> bit) & 1) xyzz_madd(acc, b, false);
     }
@@ -476,14 +478,21 @@ fixed_base_table_kernel(const Affine<typename FieldTraits<FU>::Sat> *win_bases /
 
 template <class FU>
 __global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
-fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XYZZ<FU> *out) {
+fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XYZZ<FU> *out, int wbits, int nwin) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int per = (1 << wbits) - 1;
+    uint32_t k[9];
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = scalars[8 * i + j];
+    k[8] = 0;
     XYZZ<FU> acc = XYZZ<FU>::inf();
-    for (int w = 0; w < 32; w++) {
-        const uint32_t d = (scalars[8 * i + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
+    for (int w = 0; w < nwin; w++) {
+        const int bit = w * wbits;
+        const uint64_t two = (uint64_t)k[bit >> 5] | ((uint64_t)k[(bit >> 5) + 1] << 32);
+        const uint32_t d = (uint32_t)(two >> (bit & 31)) & (uint32_t)per;
         if (d) {
-            const Affine<FU> p = ldv(table + w * 255 + (d - 1));
+            const Affine<FU> p = ldv(table + (size_t)w * per + (d - 1));
             xyzz_madd(acc, p, false);
         }
     }
@@ -853,51 +862,57 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
                            size_t n, const AffineSegs<FU> &segs, bool sync = true) {
     using FS = typename FieldTraits<FU>::Sat;
     if (n == 0) return;
+    // 8-bit windows (32 additions per point, an 8,160-entry table) for small batches, 12-bit ones (22 additions, 90,090 entries:
+    // 10 / 20 MB, L2- and MALL-resident) once the batch is worth the larger table
+    const int wbits = n >= ((size_t)1 << 17) ? 12 : 8;
+    const int nwin = (256 + wbits - 1) / wbits;
+    const size_t tab_n = (size_t)nwin * (((size_t)1 << wbits) - 1);
     FixedBaseCache::Entry *ent = nullptr;
     for (auto &x : cache.e)
-        if (x.key.size() == sizeof base && memcmp(x.key.data(), &base, sizeof base) == 0) ent = &x;
+        if (x.wbits == wbits && x.key.size() == sizeof base && memcmp(x.key.data(), &base, sizeof base) == 0) ent = &x;
     const bool miss = ent == nullptr;
     if (miss) ent = cache.e[0].stamp <= cache.e[1].stamp ? &cache.e[0] : &cache.e[1];      // replace the older one
     ent->stamp = ++cache.clock;
     if (miss) {
         // the 32 window bases 2^(8w) * base as affine points, one host inversion for all of them
-        std::vector<XYZZ<FS>> wx(32);
+        std::vector<XYZZ<FS>> wx(nwin);
         XYZZ<FS> cur = XYZZ<FS>::from_affine(base);
-        for (int w = 0; w < 32; w++) {
+        for (int w = 0; w < nwin; w++) {
             wx[w] = cur;
-            for (int q = 0; q < 8; q++) cur = xyzz_dbl(cur);
+            for (int q = 0; q < wbits; q++) cur = xyzz_dbl(cur);
         }
-        std::vector<Affine<FS>> wb(32, Affine<FS>::inf());
-        std::vector<FS> pre(32);
+        std::vector<Affine<FS>> wb(nwin, Affine<FS>::inf());
+        std::vector<FS> pre(nwin);
         FS acc = FS::one();
-        for (int w = 0; w < 32; w++) {
+        for (int w = 0; w < nwin; w++) {
             pre[w] = acc;
             if (!wx[w].is_inf()) acc = f_mul(acc, f_mul(wx[w].zz, wx[w].zzz));
         }
         FS inv = f_inv(acc);
-        for (int w = 31; w >= 0; w--) {
+        for (int w = nwin - 1; w >= 0; w--) {
             if (wx[w].is_inf()) continue;
             const FS dinv = f_mul(inv, pre[w]);
             inv = f_mul(inv, f_mul(wx[w].zz, wx[w].zzz));
             wb[w] = Affine<FS>{f_mul(wx[w].x, f_mul(dinv, wx[w].zzz)), f_mul(wx[w].y, f_mul(dinv, wx[w].zz))};
         }
         DevBuf &d_wb = cache.win_bases, &d_xyzz = cache.table_xyzz;      // kept in the cache: nothing here has to outlive a sync
-        d_wb.ensure(32 * sizeof(Affine<FS>));
-        d_xyzz.ensure(32 * 255 * sizeof(XYZZ<FU>));
-        ent->table.ensure(32 * 255 * sizeof(Affine<FU>));
-        ZK_HIP(hipMemcpy(d_wb.p, wb.data(), 32 * sizeof(Affine<FS>), hipMemcpyHostToDevice));       // 3-6 KB, from a host vector that goes away
-        hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((32 * 255 + 63) / 64), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
-                           d_xyzz.as<XYZZ<FU>>());
+        d_wb.ensure(nwin * sizeof(Affine<FS>));
+        d_xyzz.ensure(tab_n * sizeof(XYZZ<FU>));
+        ent->table.ensure(tab_n * sizeof(Affine<FU>));
+        ent->wbits = wbits;
+        ZK_HIP(hipMemcpy(d_wb.p, wb.data(), nwin * sizeof(Affine<FS>), hipMemcpyHostToDevice));       // 3-6 KB, from a host vector that goes away
+        hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((unsigned)((tab_n + 63) / 64)), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
+                           d_xyzz.as<XYZZ<FU>>(), wbits, nwin);
         ZK_HIP(hipGetLastError());
         AffineSegs<FU> ts{};
         ts.n = 1;
         ts.out_u[0] = ent->table.as<Affine<FU>>();
-        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), 32 * 255, cache.pref, ts);
+        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), tab_n, cache.pref, ts);
         ent->key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
     }
     cache.sums.ensure(n * sizeof(XYZZ<FU>));
     hipLaunchKernelGGL(fixed_base_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ent->table.as<Affine<FU>>(),
-                       reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>());
+                       reinterpret_cast<const uint32_t *>(scalars_canonical), n, cache.sums.as<XYZZ<FU>>(), wbits, nwin);
     ZK_HIP(hipGetLastError());
     batch_affine_run<FU>(ctx, cache.sums.as<XYZZ<FU>>(), n, cache.pref, segs);
     if (sync) ZK_HIP(hipStreamSynchronize(ctx->stream));
