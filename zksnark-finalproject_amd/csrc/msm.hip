@@ -864,7 +864,7 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
     if (n == 0) return;
     // 8-bit windows (32 additions per point, an 8,160-entry table) for small batches, 12-bit ones (22 additions, 90,090 entries:
     // 10 / 20 MB, L2- and MALL-resident) once the batch is worth the larger table
-    const int wbits = n >= ((size_t)1 << 17) ? 12 : 8;
+    const int wbits = n >= ((size_t)1 << 21) ? 14 : n >= ((size_t)1 << 17) ? 12 : 8;
     const int nwin = (256 + wbits - 1) / wbits;
     const size_t tab_n = (size_t)nwin * (((size_t)1 << wbits) - 1);
     FixedBaseCache::Entry *ent = nullptr;
