@@ -323,7 +323,7 @@ static void state_signature(const Lc st[3], std::vector<VarId> &ids, std::vector
 }
 
 void permute_gadget(Circuit &cs, PermTemplates &tpls, Lc st[3]) {
-    if (!tpls.enabled || !g_terms) { permute_gadget_generic(cs, st); return; }      // !g_terms: assignment-only build
+    if (!tpls.enabled) { permute_gadget_generic(cs, st); return; }
     std::vector<VarId> ids;
     std::vector<uint32_t> shape;
     std::vector<Fr> coeff;
@@ -461,7 +461,7 @@ int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit 
 // [inputs a, b + matrix witnesses] [hash_a gadget] [hash_b gadget] [two equalities] [matrix_mul + hash_c gadget] [input c +
 // equality] — with the hash_a and hash_b segments on their own threads; each segment numbers its witnesses from the offset
 // the earlier ones will have used (poseidon_hash_witnesses).  ZKG16_SYNTH_THREADS=0 builds them one after another.
-static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, const uint64_t *b, bool threaded, bool values_only = false) {
+static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, const uint64_t *b, bool threaded) {
     const size_t nn = n * n;
     std::vector<Fr> av(nn), bv(nn), cv(nn, Fr::zero());
     for (size_t i = 0; i < nn; i++) { av[i] = fr_from_u64(a[i]); bv[i] = fr_from_u64(b[i]); }
@@ -484,22 +484,16 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     Circuit &seg_d = c->add_segment(2 * nn + 2 * hw + nn + nn * (n + 1));      // hash of the product: starts after matrix_mul's witnesses
     Circuit &seg_tail = c->add_segment(0);
     std::exception_ptr err_a, err_b, err_c, err_d;
-    // values_only: only the assignment is wanted (the matrices of this circuit depend on n alone and the caller has them):
-    // every builder runs with the term bookkeeping switched off (g_terms is per thread)
     auto build_a = [&]() {
         try {
-            g_terms = !values_only;
             hash_a = poseidon_hash_native(av.data(), nn);
             ha = poseidon_hash_gadget(seg_a, ma);
-            g_terms = true;
         } catch (...) { err_a = std::current_exception(); g_terms = true; }
     };
     auto build_b = [&]() {
         try {
-            g_terms = !values_only;
             hash_b = poseidon_hash_native(bv.data(), nn);
             hb = poseidon_hash_gadget(seg_b, mb);
-            g_terms = true;
         } catch (...) { err_b = std::current_exception(); g_terms = true; }
     };
     // hash of C: entry (i, j) of the product is the symbolic sum  sum_ij + sum_k product_ijk  (constraints.rs:87-92), whose
@@ -507,7 +501,6 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     // linear combinations can be written down without waiting for matrix_mul to run
     auto build_d = [&]() {
         try {
-            g_terms = !values_only;
             hash_c = poseidon_hash_native(cv.data(), nn);
             std::vector<Lc> mc(nn);
             const Fr one = Fr::one();
@@ -519,7 +512,6 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
                 mc[e].is_const = false;
             }
             hc = poseidon_hash_gadget(seg_d, mc);
-            g_terms = true;
         } catch (...) { err_d = std::current_exception(); g_terms = true; }
     };
     // the inputs come first in arkworks' order, but their values (the native hashes) are only needed at the end: the
@@ -541,7 +533,6 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     }
     // matrix_mul (constraints.rs:78-99), on this thread
     try {
-        g_terms = !values_only;
         for (size_t i = 0; i < nn; i++) seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
         for (size_t i = 0; i < n; i++)
             for (size_t j = 0; j < n; j++) {
@@ -552,7 +543,6 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
                     seg_c.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
                 }
             }
-        g_terms = true;
     } catch (...) { err_c = std::current_exception(); g_terms = true; }
     if (threaded) { ta.join(); tb.join(); td.join(); }
     else build_d();
@@ -563,10 +553,9 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     head.instance[2] = hash_b;
     in_a.val = hash_a;
     in_b.val = hash_b;
-    Lc in_c = head.new_input(hash_c);
-    if (values_only) return;
     seg_mid.enforce_equal(ha, in_a);
     seg_mid.enforce_equal(hb, in_b);
+    Lc in_c = head.new_input(hash_c);
     seg_tail.enforce_equal(hc, in_c);
 }
 
@@ -599,22 +588,87 @@ int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_c
 // Only the full assignment z = instance || witness of the MatrixCircuit for these inputs (z: (4 + 2 n^2 + ...) x 4 limbs as
 // zkg16_circuit_export would give it; n_assign must equal that circuit's variable count): the R1CS matrices of this circuit
 // depend on n alone, so a server keeps them (and their device copy) per size and asks only for this per request.
+// The sponge's witnesses without any gadget objects: the values the PoseidonSpongeVar allocates, in its order — per
+// permutation and round the five products x^2, x^4, x^8, x^16, x^17 of every S-box input that is not a constant (the only
+// constant one is the capacity element in the first round of the first permutation).  Returns the hash; appends to out.
+static Fr poseidon_hash_witness_values(const Fr *elems, size_t count, Fr *out, size_t &n_out) {
+    const PoseidonParams &p = pparams();
+    Fr st[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t pos = 0;
+    bool first = true;
+    auto permute = [&]() {
+        for (int r = 0; r < P_ROUNDS; r++) {
+            for (int i = 0; i < 3; i++) st[i] = fp_add(st[i], p.ark[r][i]);
+            const bool full = r < P_HALF || r >= P_HALF + POSEIDON_PARTIAL;
+            for (int i = 0; i < (full ? 3 : 1); i++) {
+                const Fr x = st[i];
+                const Fr x2 = fp_sqr(x), x4 = fp_sqr(x2), x8 = fp_sqr(x4), x16 = fp_sqr(x8), x17 = fp_mul(x16, x);
+                if (!(first && r == 0 && i == 0)) {
+                    out[n_out] = x2; out[n_out + 1] = x4; out[n_out + 2] = x8; out[n_out + 3] = x16; out[n_out + 4] = x17;
+                    n_out += 5;
+                }
+                st[i] = x17;
+            }
+            Fr nst[3];
+            for (int i = 0; i < 3; i++) {
+                Fr acc = Fr::zero();
+                for (int j = 0; j < 3; j++) acc = fp_add(acc, fp_mul(st[j], p.mds[i][j]));
+                nst[i] = acc;
+            }
+            for (int i = 0; i < 3; i++) st[i] = nst[i];
+        }
+        first = false;
+    };
+    for (size_t idx = 0; idx < count; idx++) {
+        if (pos == POSEIDON_RATE) { permute(); pos = 0; }
+        st[POSEIDON_CAP + pos] = fp_add(st[POSEIDON_CAP + pos], elems[idx]);
+        pos++;
+    }
+    permute();
+    return st[POSEIDON_CAP];
+}
+
 int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *z, size_t n_assign) {
     if (!a || !b || !z || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
-    zkg16_circuit c;
+    const size_t nn = n * n, hw = poseidon_hash_witnesses(nn), ni = 4;
+    // [1, hash_a, hash_b, hash_c] | a | b | hash_a gadget | hash_b gadget | n^2 zeros | per (i, j): 0, n products | hash_c gadget
+    const size_t off_a = ni, off_b = off_a + nn, off_ha = off_b + nn, off_hb = off_ha + hw, off_mc = off_hb + hw, off_mm = off_mc + nn,
+                 off_hc = off_mm + nn * (n + 1), total = off_hc + hw;
+    if (total != n_assign) return ZKG16_ERR_BAD_ARG;
     try {
+        Fr *Z = reinterpret_cast<Fr *>(z);
+        std::vector<Fr> cv(nn);
+        for (size_t i = 0; i < nn; i++) { Z[off_a + i] = fr_from_u64(a[i]); Z[off_b + i] = fr_from_u64(b[i]); }
+        const Fr *av = Z + off_a, *bv = Z + off_b;
+        Fr ha, hb, hc;
+        size_t na = 0, nb = 0, nc = 0;
         const char *env = getenv("ZKG16_SYNTH_THREADS");
-        build_matrix_circuit(&c, n, a, b, !(env && env[0] == '0'), true);
-        const size_t ni = c.head().instance.size();
-        if (ni + c.num_witness() != n_assign) return ZKG16_ERR_BAD_ARG;
-        memcpy(z, c.head().instance.data(), ni * 32);
-        for (const auto &sg : c.segs)
-            if (!sg->witness.empty()) memcpy(z + 4 * (ni + sg->wit_base), sg->witness.data(), sg->witness.size() * 32);
+        const bool threaded = !(env && env[0] == '0');
+        auto do_a = [&]() { ha = poseidon_hash_witness_values(av, nn, Z + off_ha, na); };
+        auto do_b = [&]() { hb = poseidon_hash_witness_values(bv, nn, Z + off_hb, nb); };
+        std::thread ta, tb;
+        if (threaded) { ta = std::thread(do_a); tb = std::thread(do_b); } else { do_a(); do_b(); }
+        // matrix_mul: the pre-allocated entries and the sums' seeds are zero, the products are a_ik * b_kj in allocation order
+        for (size_t i = 0; i < nn; i++) Z[off_mc + i] = Fr::zero();
+        for (size_t i = 0; i < n; i++)
+            for (size_t j = 0; j < n; j++) {
+                Fr *blk = Z + off_mm + (i * n + j) * (n + 1);
+                blk[0] = Fr::zero();
+                Fr sum = Fr::zero();
+                for (size_t k = 0; k < n; k++) {
+                    blk[1 + k] = fp_mul(av[i * n + k], bv[k * n + j]);
+                    sum = fp_add(sum, blk[1 + k]);
+                }
+                cv[i * n + j] = sum;
+            }
+        hc = poseidon_hash_witness_values(cv.data(), nn, Z + off_hc, nc);
+        if (threaded) { ta.join(); tb.join(); }
+        if (na != hw || nb != hw || nc != hw) return ZKG16_ERR_UNSUPPORTED;      // the closed form of the sponge's witness count is off: a bug
+        Z[0] = Fr::one();
+        Z[1] = ha; Z[2] = hb; Z[3] = hc;
     } catch (const std::bad_alloc &) {
-        g_terms = true;
         return ZKG16_ERR_OOM;
     } catch (const std::exception &) {
-        g_terms = true;
         return ZKG16_ERR_UNSUPPORTED;
     }
     return ZKG16_OK;
