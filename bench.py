@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py — Groth16 (BLS12-381) proofs/s on the matrix-mul circuit, MI355X HIP path (libzkg16.so).
+"""bench.py — Groth16 (BLS12-381) proofs/s + constraints/s on the reference's matrix-mul circuit, MI355X HIP path (libzkg16.so).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path = one whole Groth16 proof of the workload (the inside of
-`Groth16::<Bls12_381>::prove`: 3 SpMV + 7 NTT + 4 G1 MSM + 1 G2 MSM + tail), with the proving key, the R1CS
-matrices and the full assignment already resident in HBM (zkg16_prove_resident).  Workload at N=1 =
-BASELINE.json configs[1]: matrix-mul 32x32 + Poseidon circuit shape (472,564 constraints, domain 2^19).
-N>1: index-range sharded proving key (every rank recomputes h, runs the five MSMs over its 1/N of the bases),
-ONE exchange per proof — an all_gather of 72 u64 of partial sums over RCCL — and the tail on every rank:
-strong scaling of one proof, as BASELINE.json's north_star asks (`--parallel replicas` is the throughput alternative:
-every rank proves its own proofs on the whole key, no exchange, weak scaling).
+N > 1 without a torch.distributed environment: this process only spawns
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a CHILD
+(before anything touches torch or the GPU) and relays its output and exit code; under torchrun (WORLD_SIZE set) it asserts
+WORLD_SIZE == --gpus and fails otherwise, so a 1-GPU number can never be reported as an N-GPU one.
 
-At N=1 the line also carries `throughput_in_flight`: after the contract's timed region, the same proofs with
-`--in-flight` (default 2) of them in flight at once, one library ctx per host thread — what a multi-worker server gets.
+One "step" = one pass of the hot path = one whole Groth16 proof of the workload (the inside of `Groth16::<Bls12_381>::prove`,
+/root/reference/src/arkworks/backend/matrix_proof.rs:139-140: 3 SpMV + 7 NTT + 4 G1 MSM + 1 G2 MSM + tail) with the proving
+key, the R1CS matrices and the full assignment already resident in HBM (zkg16_prove_resident).
+Workload at N = 1 = the LARGEST single-GPU configuration of BASELINE.json: MatrixCircuit 128x128 + Poseidon — 10,706,932
+constraints, 8,675,313 witness variables, domain 2^24 — synthesized by the C++ mirror of the reference's circuit on the
+reference bench's all-ones inputs (bench/matrix.py:11).  The key is a REAL Groth16 key (zkg16_setup_resident from a seeded
+trapdoor), and the last proof of the timed region is VERIFIED with the pairing verifier (zkg16_verify) after the region:
+`proof_verified`; a failure exits non-zero.  Extra legs in the same JSON line (N = 1): the 46x46 (largest 2^20 domain) and
+32x32 (configs[1]) circuits, each verified; `end_to_end` = what the reference times as `proving_time` (host synthesis + the
+host-pointer entry zkg16_prove); `cpu_baseline` = the CPU oracle (a port, oracle/) timed directly on the 32x32 circuit on all
+host threads — its proof must equal the GPU's 32x32 proof bit for bit (`oracle_match`) — and on one thread at 16x16.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate_g1) from HIP-event pairs
-recorded on the library's stream during the timed region; `cpu_baseline` times the CPU oracle (a port, see
-oracle/g16_oracle.c) on a bounded sample on rank 0 at N=1.
+N > 1 (`--parallel shard`, default): ONE proof over N ranks with rank roles from zkg16_shard_plan (the first k ranks run the
+witness map and share h_query; every rank takes the share of the z-side index ranges that lets all finish together), ONE
+exchange per proof — an all_gather of 77 words of partial sums over RCCL — and the tail on every rank: strong scaling.
+`--parallel replicas`: every rank proves its own proofs on the whole key, no exchange (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (msm_accumulate_g1) from HIP-event pairs recorded on
+the library's own stream during the timed region; `traffic` / `alu.peak` are read from the profile summaries committed under
+profiles/ for this configuration (null when there is none).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,115 +42,153 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--matrix-n", type=int, default=32, help="n of the n x n matrix-mul circuit (32 = configs[1], 46 = 2^20 domain)")
-    ap.add_argument("--workload", default="matrix", choices=["matrix", "prime_like"],
-                    help="matrix = the reference's MatrixCircuit (metric workload); prime_like = bit-heavy circuit of configs[4]'s shape")
-    ap.add_argument("--synthetic-rows", action="store_true", help="shape-exact synthetic rows instead of the synthesized MatrixCircuit")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--matrix-n", type=int, default=128, help="n of the n x n matrix-mul circuit (128 = largest single-GPU config, 2^24 domain)")
+    ap.add_argument("--workload", default="matrix", choices=["matrix", "prime"],
+                    help="matrix = the reference's MatrixCircuit (metric workload); prime = the reference's PrimeCircuit (configs[4])")
+    ap.add_argument("--legs", default="46,32", help="N = 1: further matrix sizes measured after the timed region (comma list, '' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host synthesis + host-pointer prove) leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: several ranks on one GPU)")
-    ap.add_argument("--cpu-sample-n", type=int, default=16, help="matrix size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample-n", type=int, default=32, help="matrix size the CPU baseline proves on all threads")
+    ap.add_argument("--cpu-1t-n", type=int, default=16, help="matrix size the CPU baseline proves on one thread")
     ap.add_argument("--parallel", default="shard", choices=["shard", "replicas"],
                     help="N > 1: shard = one proof's index ranges over the ranks (north_star; strong scaling); "
                          "replicas = every rank proves its own proofs on the whole key (no exchange; weak scaling)")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="N = 1: after the contract's timed region, also report throughput with this many proofs in flight "
-                         "(one ctx per host thread, as one ctx per server worker would run); 0/1 = skip")
+    ap.add_argument("--h-ranks", type=int, default=0, help="N > 1, shard: ranks that run the witness map (0 = cost model; N = equal split)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="N = 1: after the timed region, also report throughput with this many proofs in flight (one ctx per host thread)")
+    ap.add_argument("--seed", type=int, default=2026)
     return ap.parse_args()
 
 
-def rand_fr_mont(rng):
-    # any 4 limbs < 2^254 are a valid Montgomery representative of some Fr element
-    v = rng.integers(0, 1 << 62, size=4, dtype=np.uint64)
-    return v
+def spawn_ranks(args):
+    """--gpus N > 1 outside torchrun: launch N ranks as a child process, before this process has touched torch or the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stderr.write("bench.py: spawning %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
-def make_key(dev, r1cs, shp, seed):
-    """A structurally faithful proving key for the workload: every query element is a valid subgroup point
-    [k]G with random k (fixed-base kernel on the GPU), and a query entry is the point at infinity exactly where
-    arkworks' generator would produce one (variable absent from that side of the R1CS)."""
-    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
-    rng = np.random.default_rng(seed)
-    nv, ni = shp["num_vars"], shp["num_instance"]
-    n_h = shp["domain"] - 1
-
-    def pts(group, n):
-        gen = g1_generator() if group == "g1" else g2_generator()
-        sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
-        p, inf = dev.fixed_base(group, gen, sc)
-        return p
-
-    in_a = np.zeros(nv, dtype=bool)
-    in_a[r1cs["a"][1]] = True
-    in_a[:ni] = True                       # instance rows of the LibsnarkReduction put L_{nc+k} on the A side
-    in_b = np.zeros(nv, dtype=bool)
-    in_b[r1cs["b"][1]] = True
-    pk = {}
-    pk["a_query"] = pts("g1", nv)
-    pk["a_inf"] = (~in_a).astype(np.uint8)
-    pk["b_g1_query"] = pts("g1", nv)
-    pk["b_g1_inf"] = (~in_b).astype(np.uint8)
-    pk["b_g2_query"] = pts("g2", nv)
-    pk["b_g2_inf"] = pk["b_g1_inf"].copy()
-    pk["h_query"] = pts("g1", n_h)
-    pk["l_query"] = pts("g1", nv - ni)
-    single1 = pts("g1", 3)
-    single2 = pts("g2", 3)
-    pk["alpha_g1"], pk["beta_g1"], pk["delta_g1"] = single1[0], single1[1], single1[2]
-    pk["beta_g2"], pk["delta_g2"] = single2[1], single2[2]
-    return pk
+def fr_mont(x):
+    v = (x << 256) % R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
-def cpu_baseline(sample_n, target_nc, threads, dev=None):
-    """Times the CPU oracle (port of the arkworks algorithms; oracle/) on a bounded sample of the same workload
-    family and scales by constraint count to the metric's unit (proofs/s of the target circuit)."""
-    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+def draw_key_inputs(seed):
+    """The trapdoor (tau, alpha, beta, gamma, delta) and generators a request would draw from its rng (upstream: generator.rs)."""
     import random
+    from zksnark_finalproject_amd.device import scalar_mul
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    rng = random.Random(seed)
+    trap = np.stack([fr_mont(rng.randrange(1, R_MOD)) for _ in range(5)])
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    return trap, scalar_mul("g1", g1_generator(), k)[0], scalar_mul("g2", g2_generator(), k)[0]
 
+
+def synthesize(workload, n, x=None):
+    """-> (SynthesizedCircuit, seconds, description).  matrix: all-ones n x n inputs as bench/matrix.py:11."""
+    t0 = time.perf_counter()
+    if workload == "prime":
+        from zksnark_finalproject_amd.circuits import prime_circuit
+        circ = prime_circuit(0x123456789ABCDEF if x is None else x, 32)
+        desc = ("Fermat-prime circuit (PrimeCircuit mirror, BASELINE configs[4]: SHA-256 + 3 Fermat bases, 20-bit modpow): %d constraints, "
+                "%d witness vars, domain 2^%d" % (circ.num_constraints, circ.num_witness, circ.domain.bit_length() - 1))
+    else:
+        from zksnark_finalproject_amd.circuits import matrix_circuit
+        ones = np.ones((n, n), dtype=np.uint64)
+        circ = matrix_circuit(ones, ones)
+        desc = ("matrix-mul %dx%d + Poseidon MatrixCircuit: %d constraints, %d witness vars, domain 2^%d"
+                % (n, n, circ.num_constraints, circ.num_witness, circ.domain.bit_length() - 1))
+    return circ, time.perf_counter() - t0, desc
+
+
+def profile_lookup(key):
+    """Numbers that come from committed profile summaries (profiles/bench_constants_r2.json, written by tools/pmc_to_json.py from
+    the rocprofv3 --pmc / microbench logs next to it); None when the summary has no entry for this configuration."""
+    path = os.path.join(ROOT, "profiles", "bench_constants_r2.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    cur = d
+    for k in key:
+        if not isinstance(cur, dict) or k not in cur:
+            return None
+        cur = cur[k]
+    return cur
+
+
+def cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs, headline_nc):
+    """Times the CPU oracle (a port of the arkworks algorithms; oracle/) directly: the 32x32 MatrixCircuit on all host threads
+    (its proof is compared with the GPU's for the same key, r, s) and the 16x16 one on a single thread."""
+    sys.path[:0] = [os.path.join(ROOT, "oracle")]
     import oracle as orc
-    import synth
-    from helpers import fr_mont
+    trap, g1, g2 = key_inputs
+    threads = min(os.cpu_count() or 1, 16)
 
-    from zksnark_finalproject_amd.circuits import matrix_circuit
-    circ = matrix_circuit(np.ones((sample_n, sample_n), dtype=np.uint64), np.ones((sample_n, sample_n), dtype=np.uint64))
-    r1cs, z = circ.r1cs, circ.z
-    shp = dict(nc=circ.num_constraints, num_vars=circ.num_vars, domain=circ.domain)
-    rng = random.Random(7)
-    # the sample's key: points from the device's fixed-base kernel when a device is at hand (untimed; the timed part is the
-    # CPU prover alone)
-    pk, _ = synth.make_pk(orc, r1cs, shp["num_vars"], rng, point_gen=dev.fixed_base if dev is not None else None)
+    def host_key(n):
+        circ, _, _ = synthesize("matrix", n)
+        rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+        pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)      # untimed: the timed part is the CPU prover alone
+        dev.r1cs_free(rh)
+        return circ, pk
+
+    out = {"kind": "port", "unit": "proofs/s"}
+    n = args.cpu_sample_n
+    circ, pk = host_key(n)
     used = orc.set_threads(threads)
-    t0 = time.time()
-    orc.prove(pk, fr_mont(12345), fr_mont(67890), r1cs, z)
-    dt = time.time() - t0
-    cps = shp["nc"] / dt
-    # the same prover on one thread (the published curve looks single-threaded), on a quarter-size sample
-    small = matrix_circuit(np.ones((sample_n // 2, sample_n // 2), dtype=np.uint64), np.ones((sample_n // 2, sample_n // 2), dtype=np.uint64))
-    pk1, _ = synth.make_pk(orc, small.r1cs, small.num_vars, rng, point_gen=dev.fixed_base if dev is not None else None)
+    r, s = rs
+    t0 = time.perf_counter()
+    oproof, oinf = orc.prove(pk, r, s, circ.r1cs, circ.z)
+    dt = time.perf_counter() - t0
+    out["cores"] = used
+    out["measured"] = {"n": n, "constraints": circ.num_constraints, "seconds": dt, "proofs_per_sec": 1.0 / dt,
+                       "constraints_per_sec": circ.num_constraints / dt, "cores": used}
+    if gpu_proof_n32 is not None and n == 32:
+        out["oracle_match"] = bool(np.array_equal(oproof, gpu_proof_n32[0]) and np.array_equal(oinf, gpu_proof_n32[1]))
+    del pk
+    n1 = args.cpu_1t_n
+    circ1, pk1 = host_key(n1)
     orc.set_threads(1)
-    t1 = time.time()
-    orc.prove(pk1, fr_mont(12345), fr_mont(67890), small.r1cs, small.z)
-    dt1 = time.time() - t1
+    t0 = time.perf_counter()
+    orc.prove(pk1, r, s, circ1.r1cs, circ1.z)
+    dt1 = time.perf_counter() - t0
     orc.set_threads(threads)
-    return dict(value=cps / target_nc, unit="proofs/s", cores=used, kind="port",
-                one_thread={"value": small.num_constraints / dt1 / target_nc, "unit": "proofs/s", "cores": 1,
-                            "sample": "n=%d (%d constraints) in %.2f s" % (sample_n // 2, small.num_constraints, dt1)},
-                sample="oracle prove of the same MatrixCircuit at n=%d (%d constraints, domain 2^%d) in %.2f s on %d threads "
-                       "(OpenMP: one task per MSM window, as ark's `parallel` feature); scaled by constraint count to n=32-equivalent proofs/s"
-                       % (sample_n, shp["nc"], shp["domain"].bit_length() - 1, dt, used),
-                constraints_per_sec=cps)
+    out["one_thread"] = {"n": n1, "constraints": circ1.num_constraints, "seconds": dt1, "proofs_per_sec": 1.0 / dt1,
+                         "constraints_per_sec": circ1.num_constraints / dt1, "cores": 1}
+    # the metric's unit on the headline workload: scaled by constraint count from the all-threads measurement
+    out["value"] = (circ.num_constraints / dt) / headline_nc
+    out["sample"] = ("MEASURED: oracle prove of the %dx%d MatrixCircuit (%d constraints) in %.2f s on %d threads (OpenMP: one task per MSM "
+                     "window, as ark's `parallel` feature) and of the %dx%d one (%d constraints) in %.2f s on 1 thread; SCALED: `value` = the "
+                     "all-threads constraints/s divided by the headline circuit's %d constraints"
+                     % (n, n, circ.num_constraints, dt, used, n1, n1, circ1.num_constraints, dt1, headline_nc))
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)           # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs\n" % (args.gpus, world, world, args.gpus))
+        sys.exit(2)
     import torch
     dist = None
     on_gpu = args.dist_backend == "nccl"
@@ -150,32 +200,33 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write("bench.py: process group has %d ranks, --gpus %d\n" % (dist.get_world_size(), args.gpus))
+            sys.exit(2)
     from zksnark_finalproject_amd import Device
-    from zksnark_finalproject_amd.workloads import matmul_like_r1cs
+    from zksnark_finalproject_amd.device import shard_plan, verify
 
     dev = Device(dev_index)
-    if args.workload == "prime_like":
-        from zksnark_finalproject_amd.workloads import prime_like_r1cs
-        r1cs, z, shp = prime_like_r1cs()
-    elif args.synthetic_rows:
-        r1cs, z, shp = matmul_like_r1cs(args.matrix_n)      # same seed on every rank
-    else:
-        # the reference's MatrixCircuit itself (C++ mirror, csrc/circuits.hip) on bench/matrix.py:11's all-ones inputs
-        from zksnark_finalproject_amd.circuits import matrix_circuit
-        n = args.matrix_n
-        circ = matrix_circuit(np.ones((n, n), dtype=np.uint64), np.ones((n, n), dtype=np.uint64))
-        r1cs, z = circ.r1cs, circ.z
-        shp = dict(n=n, nc=circ.num_constraints, num_instance=circ.num_instance, num_witness=circ.num_witness,
-                   num_vars=circ.num_vars, domain=circ.domain)
     sharded = world > 1 and args.parallel == "shard"
-    pk = make_key(dev, r1cs, shp, seed=0xC0FFEE)
-    ph = dev.pk_load(pk, shp["num_instance"], shard_index=rank if sharded else 0, shard_count=world if sharded else 1)
-    rh = dev.r1cs_load(r1cs, shp["num_vars"])
-    wh = dev.witness_load(z)
-    if not (world == 1 and args.in_flight > 1):
-        del pk                       # kept for the proofs-in-flight leg's further contexts (created after the timed region)
+    key_inputs = draw_key_inputs(args.seed)           # same seed on every rank -> the same key on every rank
+    trap, g1, g2 = key_inputs
+
+    circ, synth_s, desc = synthesize(args.workload, args.matrix_n)
+    shp = dict(nc=circ.num_constraints, num_instance=circ.num_instance, num_witness=circ.num_witness, num_vars=circ.num_vars, domain=circ.domain)
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    t0 = time.perf_counter()
+    ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
+    setup_s = time.perf_counter() - t0
+    plan, h_ranks = None, 1
+    if sharded:
+        plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks)
+        z_lo, z_hi, h_lo, h_hi, blind = plan[rank]
+        full = ph
+        ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device; the whole key is dropped again
+        dev.pk_free(full)
+    wh = dev.witness_load(circ.z)
     rng = np.random.default_rng(99)
-    rs = [(rand_fr_mont(rng), rand_fr_mont(rng)) for _ in range(args.steps + args.warmup)]
+    rs = [(fr_mont(int.from_bytes(rng.bytes(31), "little")), fr_mont(int.from_bytes(rng.bytes(31), "little"))) for _ in range(args.steps + args.warmup + 2)]
 
     xdev = "cuda" if on_gpu else "cpu"
     if sharded:
@@ -198,6 +249,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    proof = inf = None
     for i in range(args.warmup):
         proof, inf = one_proof(*rs[i])
     dev.kernel_stats_reset()
@@ -215,16 +267,73 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- correctness gate, outside the timed region: the last timed proof must satisfy the Groth16 pairing equation for the real key
+    verified = verify(vk, circ.public_inputs, proof, inf) if proof is not None else False
+    if world > 1:
+        flag = torch.tensor([1 if verified else 0], dtype=torch.int64, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
     stages = dev.last_timings()
+    acc = dev.kernel_stats("msm_accumulate_g1")
+    acc2 = dev.kernel_stats("msm_accumulate_g2")
+
+    extra_out = {}
+    if rank == 0 and world == 1:
+        # ---- stand-alone witness map and one transform of the workload's domain (second kernel family of the path)
+        try:
+            log_n = shp["domain"].bit_length() - 1
+            dev.bench_ntt(log_n, 1, 1, 2)
+            ntt_ms = dev.bench_ntt(log_n, 1, 1, 10)
+            gbs = 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9
+            extra_out["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_cols_u + ntt_pass_rows_u (one coset-inverse transform of 2^%d)" % log_n,
+                                         "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "ms": ntt_ms, "transforms_per_proof": 7,
+                                         "traffic": profile_lookup(["n%d" % args.matrix_n, "ntt_transform_traffic_bytes"]),
+                                         "note": "64 algorithmic bytes per element (read once, written once); integer-ALU bound too"}
+            extra_out["witness_map_standalone_ms"] = dev.bench_witness_map(rh, wh, 3)
+        except Exception as e:      # noqa: BLE001 - an extra leg must never cost the contract line
+            extra_out["roofline_ntt"] = {"error": repr(e)}
+
+        # ---- end to end = the reference's `proving_time` (matrix_proof.rs:138-145): Groth16::prove re-synthesizes the circuit on
+        # the host and hands matrices + assignment to the prover; here: C++ synthesis + zkg16_prove (host pointers, uploads inside)
+        if not args.no_e2e:
+            try:
+                r, s = rs[-1]
+                t1 = time.perf_counter()
+                c2, syn2, _ = synthesize(args.workload, args.matrix_n)
+                t2 = time.perf_counter()
+                p2, i2 = dev.prove(ph, r, s, c2.r1cs, c2.z)
+                t3 = time.perf_counter()
+                ok2 = verify(vk, c2.public_inputs, p2, i2)
+                e2e = {"seconds": t3 - t1, "proofs_per_sec": 1.0 / (t3 - t1), "constraints_per_sec": shp["nc"] / (t3 - t1),
+                       "host_synthesis_s": t2 - t1, "prove_host_pointers_s": t3 - t2, "proof_verified": bool(ok2),
+                       "note": "host synthesis (C++ mirror, full R1CS + assignment) + zkg16_prove with host pointers (matrices and "
+                               "assignment uploaded over PCIe inside the call); the key stays resident, as the reference holds its pk"}
+                if args.workload == "matrix":
+                    # a server that kept the matrices of this size (they depend on n alone): assignment only + resident prove
+                    from zksnark_finalproject_amd.circuits import matrix_witness
+                    ones = np.ones((args.matrix_n, args.matrix_n), dtype=np.uint64)
+                    t1 = time.perf_counter()
+                    z2 = matrix_witness(ones, ones, shp["num_vars"])
+                    w2 = dev.witness_load(z2)
+                    p3, i3 = dev.prove_resident(ph, rh, w2, r, s)
+                    t2 = time.perf_counter()
+                    dev.witness_free(w2)
+                    e2e["cached_matrices"] = {"seconds": t2 - t1, "proofs_per_sec": 1.0 / (t2 - t1), "same_proof": bool(np.array_equal(p3, p2)),
+                                              "note": "assignment-only synthesis + upload + zkg16_prove_resident on the matrices kept per size"}
+                del c2
+                extra_out["end_to_end"] = e2e
+            except Exception as e:      # noqa: BLE001
+                extra_out["end_to_end"] = {"error": repr(e)}
+
     in_flight = None
-    extra = []                       # further contexts on the same GPU, made only now so that the contract's region saw one ctx
     if world == 1 and args.in_flight > 1:
+        import threading
+        extra = []
         for _ in range(args.in_flight - 1):
             d2 = Device(dev_index)
-            extra.append((d2, d2.pk_load(pk, shp["num_instance"]), d2.r1cs_load(r1cs, shp["num_vars"]), d2.witness_load(z)))
-        del pk
-    if extra:
-        import threading
+            r2 = d2.r1cs_load(circ.r1cs, circ.num_vars)
+            p2, _ = d2.setup_resident(r2, circ.num_instance, trap, g1, g2)
+            extra.append((d2, p2, r2, d2.witness_load(circ.z)))
         lanes = [(dev, ph, rh, wh)] + extra
         per = max(args.steps, 4)
 
@@ -249,85 +358,118 @@ def main():
         for d2, *_ in extra:
             d2.close()
 
+    # ---- free the headline workload before the smaller legs
+    headline_z = circ.z
+    for f, h in ((dev.pk_free, ph), (dev.witness_free, wh), (dev.r1cs_free, rh)):
+        f(h)
+    del circ
+
+    legs = []
+    gpu_proof_n32 = None
+    if rank == 0 and world == 1 and args.workload == "matrix":
+        for n in [int(x) for x in args.legs.split(",") if x.strip()]:
+            try:
+                c, syn, d_ = synthesize("matrix", n)
+                r_h = dev.r1cs_load(c.r1cs, c.num_vars)
+                t1 = time.perf_counter()
+                p_h, v_k = dev.setup_resident(r_h, c.num_instance, trap, g1, g2)
+                set_s = time.perf_counter() - t1
+                w_h = dev.witness_load(c.z)
+                dev.prove_resident(p_h, r_h, w_h, *rs[0])
+                k = max(3, min(args.steps, 20))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for j in range(k):
+                    pr, pi = dev.prove_resident(p_h, r_h, w_h, *rs[j % (len(rs) - 1)])
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t1) / k
+                pr, pi = dev.prove_resident(p_h, r_h, w_h, *rs[-1])
+                if n == 32:
+                    gpu_proof_n32 = (pr, pi)
+                legs.append({"workload": d_, "n": n, "ms_per_step": d1 * 1e3, "value": 1.0 / d1, "unit": "proofs/s", "steps": k,
+                             "constraints_per_sec": c.num_constraints / d1, "proof_verified": bool(verify(v_k, c.public_inputs, pr, pi)),
+                             "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings()})
+                for f, h in ((dev.pk_free, p_h), (dev.witness_free, w_h), (dev.r1cs_free, r_h)):
+                    f(h)
+            except Exception as e:      # noqa: BLE001
+                legs.append({"n": n, "error": repr(e)})
+
     if rank == 0:
         total_proofs = args.steps * (world if (world > 1 and not sharded) else 1)
-        acc = dev.kernel_stats("msm_accumulate_g1")
-        acc2 = dev.kernel_stats("msm_accumulate_g2")
         # algorithmic bytes of one G1 bucket-accumulation launch: every (base, scalar) term once = (96 + 32) B per term
-        # (SURVEY.md 8d); terms per launch = MSM length of that launch, averaged over the 4 G1 MSMs of a proof.
-        nshard = world if sharded else 1
-        nz = (shp["num_vars"] + 3 + nshard - 1) // nshard
-        nh = (shp["domain"] - 1 + nshard - 1) // nshard
-        terms_per_launch = (3 * nz + nh) / 4.0
+        # (SURVEY.md 8d); terms per launch = what the launches of this rank actually processed (event-pair units)
+        launches = max(acc["launches"], 1)
+        terms_per_launch = acc["units"] / launches
         alg_bytes = 128.0 * terms_per_launch
-        avg_ms = acc["ms"] / max(acc["launches"], 1)
+        avg_ms = acc["ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic of one msm_accumulate_g1 launch from rocprofv3 PMC passes of this same command (profiles/
-        # rocprofv3_pmc_r1_fetch_write.txt: FETCH_SIZE + WRITE_SIZE, calibrated on ntt_pass_cols: no 2x for 112-B gathers);
-        # only known for the default workload on one GPU
-        traffic = 1.05e9 if (world == 1 and args.matrix_n == 32 and args.workload == "matrix") else None
+        cfg_key = "n%d" % args.matrix_n if args.workload == "matrix" else args.workload
+        traffic = profile_lookup([cfg_key, "msm_accumulate_g1_traffic_bytes"]) if world == 1 else None
         out = {
             "metric": "groth16_proofs_per_sec", "value": total_proofs / dt, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": ("Fermat-prime-shaped boolean circuit (BASELINE configs[4] shape, synthetic rows): %d constraints, %d witness vars, domain 2^%d; "
-                                    "pk/R1CS/assignment resident in HBM" % (shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1))
-                       if args.workload == "prime_like" else
-                                   "matrix-mul %dx%d + Poseidon circuit (BASELINE configs[1] when n=32): %d constraints, %d witness vars, domain 2^%d; "
-                                   "pk/R1CS/assignment resident in HBM; %s; structurally faithful random-point key"
-                                   % (args.matrix_n, args.matrix_n, shp["nc"], shp["num_witness"], shp["domain"].bit_length() - 1,
-                                      "synthetic shape-exact rows" if args.synthetic_rows else "R1CS + witness synthesized by the C++ mirror of the reference's MatrixCircuit on all-ones inputs"),
+            "data": "the reference's circuit on its bench driver's inputs (all-ones matrices, bench/matrix.py:11); real Groth16 key from a seeded trapdoor",
+            "proof_verified": bool(verified),
+            "config": {"workload": desc + "; pk/R1CS/assignment resident in HBM; real key (zkg16_setup_resident), last timed proof verified (zkg16_verify)",
                        "parallelism": "1 GPU" if world == 1 else
-                                      ("index-range sharded pk over %d GPUs + 1 all_gather(77 words)/proof" % world if sharded else
+                                      ("%d GPUs, one proof: %d rank(s) run the witness map and share h_query, z-side index ranges by cost model "
+                                       "(zkg16_shard_plan); 1 all_gather(77 words)/proof" % (world, h_ranks) if sharded else
                                        "%d replicas: every GPU proves its own proofs on the whole key, no exchange" % world)},
             "constraints_per_sec": shp["nc"] * total_proofs / dt,
+            "setup_resident_s": setup_s, "host_synthesis_s": synth_s,
             "stage_ms_last_proof": stages,
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_g1", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "terms_per_launch": acc["units"] / max(acc["launches"], 1),
-                         "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (~4,700 VALU "
-                                 "instructions) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command "
-                                 "(bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
+                         "terms_per_launch": terms_per_launch,
+                         "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (~3,700 "
+                                 "v_mad_u64_u32) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command from "
+                                 "profiles/ (bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
+        if plan is not None:
+            out["config"]["shard_plan"] = [{"rank": i, "z": [p[0], p[1]], "h": [p[2], p[3]], "blinding": p[4]} for i, p in enumerate(plan)]
         # the bound that does apply: mixed additions per second against the same addition in a bare register-resident loop
-        # (tools/microbench.hip, profiles/microbench_r1_uform.txt: 6.75 G add/s at 2 waves/SIMD on this part)
-        tpl = acc["units"] / max(acc["launches"], 1)
-        nwin = 254 // (16 if tpl >= (1 << 20) else 15 if tpl >= (1 << 17) else 13 if tpl >= (1 << 14) else 9) + 1
-        # entries per launch: a scalar 1 gives one entry, a scalar 0 none, everything else one per window (L, A, B1 share
-        # z; H is uniform); averaged over the four G1 launches like avg_ms
-        R_MOD = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
-        one = np.array([((1 << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-        zz = np.asarray(z, dtype=np.uint64).reshape(-1, 4)
-        n_one = int(np.all(zz == one, axis=1).sum())
-        n_zero = int(np.all(zz == 0, axis=1).sum())
-        z_entries = ((zz.shape[0] - n_one - n_zero) * nwin + n_one) / nshard
-        h_entries = nh * (254 // (16 if nh >= (1 << 20) else 15 if nh >= (1 << 17) else 13 if nh >= (1 << 14) else 9) + 1)
-        gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": 6.75, "unit": "G mixed additions/s", "frac": gadd / 6.75,
-                      "note": "entries = one per window for every scalar other than 0 and 1 (B1's density filter not counted: slight "
-                              "over-estimate); peak = the XYZZ mixed addition alone in a register-resident loop at the kernel's occupancy"}
-        # second kernel family of the path: one transform of the workload's domain, timed alone after the timed region
-        # (64 algorithmic bytes per element: each element read once and written once)
-        try:
-            log_n = shp["domain"].bit_length() - 1
-            dev.bench_ntt(log_n, 1, 1, 2)
-            ntt_ms = dev.bench_ntt(log_n, 1, 1, 10)
-            out["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_cols_u + ntt_pass_rows_u (one coset-inverse transform of 2^%d)" % log_n,
-                                   "achieved": 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                   "frac": 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9 / 8000.0, "ms": ntt_ms, "transforms_per_proof": 7,
-                                   "note": "integer-ALU bound too: ~7 Fr products per element per pass, two passes"}
-        except Exception as e:      # noqa: BLE001 - the extra leg must never cost the contract line
-            out["roofline_ntt"] = {"error": repr(e)}
+        nshard = world if sharded else 1
+        if world == 1:
+            one = fr_mont(1)
+            zz = np.asarray(headline_z, dtype=np.uint64).reshape(-1, 4)
+            n_one = int(np.all(zz == one, axis=1).sum())
+            n_zero = int(np.all(zz == 0, axis=1).sum())
+            nz, nh = zz.shape[0], shp["domain"] - 1
+
+            def nwin(n):
+                return 254 // (16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
+            z_entries = (nz - n_one - n_zero) * nwin(nz) + n_one
+            h_entries = nh * nwin(nh)
+            gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
+            out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": peak, "unit": "G mixed additions/s",
+                          "frac": (gadd / peak) if peak else None,
+                          "note": "entries = one per window for every scalar other than 0 and 1 (B1's density filter not counted: slight "
+                                  "over-estimate); peak = the same XYZZ mixed addition in a bare register-resident loop at the kernel's "
+                                  "occupancy (tools/microbench.hip; profiles/bench_constants_r2.json names the log)"}
+        out.update(extra_out)
+        if legs:
+            out["legs"] = legs
         if in_flight:
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, shp["nc"], min(os.cpu_count() or 1, 16), dev)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs[-1], shp["nc"])
+            except Exception as e:      # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     dev.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if not verified:
+        sys.stderr.write("bench.py: the timed proof did NOT verify\n")
+        sys.exit(3)
+    if rank == 0 and world == 1 and isinstance(locals().get("out", {}).get("cpu_baseline"), dict) and out["cpu_baseline"].get("oracle_match") is False:
+        sys.stderr.write("bench.py: the GPU proof of the 32x32 circuit differs from the oracle's\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -67,6 +67,30 @@ ZKG16_API int zkg16_pk_load(zkg16_ctx *ctx,
                   const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
                   const uint64_t delta_g1[12], const uint64_t delta_g2[24],
                   size_t num_instance, int shard_index, int shard_count, uint64_t *pk_handle);
+/* The same with explicit index ranges instead of an equal split: this ctx keeps [z_lo, z_hi) of a_query / b_g1_query /
+ * b_g2_query (and the l_query entries of those variables) and [h_lo, h_hi) of h_query; `blinding` != 0 on exactly one rank of a
+ * proof (its MSMs carry the r*delta, s*delta, -rs*delta terms).  A rank with an empty h range skips the witness map and the H
+ * MSM, one with an empty z range (and blinding == 0) skips the four z-side MSMs: ranks may take different roles (zkg16_shard_plan). */
+ZKG16_API int zkg16_pk_load_range(zkg16_ctx *ctx,
+                  const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
+                  const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
+                  const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
+                  const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
+                  const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
+                  const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                  const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                  size_t num_instance, size_t z_lo, size_t z_hi, size_t h_lo, size_t h_hi, int blinding, uint64_t *pk_handle);
+/* A shard cut out of a whole key that is already resident on this ctx (zkg16_setup_resident, or zkg16_pk_load with shard 0 of 1):
+ * device-to-device copies only.  The source handle stays valid (free it with zkg16_pk_free when the shard is all a rank needs). */
+ZKG16_API int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t pk_handle, size_t z_lo, size_t z_hi, size_t h_lo, size_t h_hi, int blinding,
+                   uint64_t *shard_handle);
+/* Rank roles for one proof over n_ranks GPUs (host-only, no ctx, no GPU).  ranges: n_ranks x 4 = z_lo, z_hi, h_lo, h_hi per rank;
+ * blinding: n_ranks flags (exactly one set).  The first *h_ranks_out ranks run the witness map and share h_query by index range;
+ * every rank gets the share of the z ranges that makes all ranks finish together under a cost model in G1 mixed additions
+ * (b_density = fraction of variables present in the B queries, <= 0 for the default 0.8; h_ranks = 0 lets the model choose,
+ * h_ranks = n_ranks gives the equal split of zkg16_pk_load's shard_index / shard_count). */
+ZKG16_API int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks,
+                     uint64_t *ranges /* n_ranks x 4 */, uint8_t *blinding /* n_ranks */, int *h_ranks_out);
 ZKG16_API void zkg16_pk_free(zkg16_ctx *ctx, uint64_t pk_handle);
 
 /* ---- R1CS residency (ark_relations `ConstraintMatrices<Fr>` as CSR; matrices are per-circuit constants).
@@ -189,6 +213,7 @@ ZKG16_API int zkg16_scalar_mul_g2(const uint64_t base[24], const uint64_t k_cano
 
 /* ---- device-resident stage benches (inputs uploaded once, op repeated on device) ---------------- */
 ZKG16_API int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int iters, float *ms_per_iter);
+ZKG16_API int zkg16_bench_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, int iters, float *ms_per_iter);
 ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t *bases, const uint8_t *inf,
                     const uint64_t *scalars_canonical, size_t n, int iters, float *ms_per_iter,
                     uint64_t *out_affine, uint8_t *out_inf);
@@ -211,6 +236,7 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "wm_concurrent"  0 = witness map in order on the main stream (default: own stream)  "fixup_aux"      1 = fix-ups on the reduction stream
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
+ *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
  * Unknown names return ZKG16_ERR_UNSUPPORTED. */
 ZKG16_API int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value);
 

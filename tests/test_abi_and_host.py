@@ -73,9 +73,10 @@ def test_workload_is_satisfiable(oracle):
     assert not h[-1].any()           # deg h <= N-2
 
 
-def _shard_partials(oracle, pk, r1cs, z, r, s, n_shards):
+def _shard_partials(oracle, pk, r1cs, z, r, s, n_shards, plan=None):
     """What each rank's zkg16_prove_partial returns, computed with the oracle: MSMs over index-range shards,
-    with the r*delta / s*delta / -rs*delta terms riding in shard 0."""
+    with the r*delta / s*delta / -rs*delta terms riding in the blinding shard (shard 0 of the equal split).
+    plan: per-rank (z_lo, z_hi, h_lo, h_hi, blinding) as zkg16_shard_plan yields them; None = the equal split."""
     ni = r1cs["num_inputs"]
     zc = oracle.fr_to_canonical(z)
     hc = oracle.fr_to_canonical(oracle.witness_map(r1cs, z))
@@ -86,15 +87,19 @@ def _shard_partials(oracle, pk, r1cs, z, r, s, n_shards):
     l_inf = np.concatenate([np.ones(ni, np.uint8), pk["l_inf"]])
     parts, infs = [], []
     for k in range(n_shards):
-        lo, hi = n * k // n_shards, n * (k + 1) // n_shards
-        hlo, hhi = nh * k // n_shards, nh * (k + 1) // n_shards
+        if plan is None:
+            lo, hi = n * k // n_shards, n * (k + 1) // n_shards
+            hlo, hhi = nh * k // n_shards, nh * (k + 1) // n_shards
+            blind = k == 0
+        else:
+            lo, hi, hlo, hhi, blind = plan[k]
         rec, finf = [], []
         pH, fH = oracle.msm("g1", pk["h_query"][hlo:hhi], hc[hlo:hhi], pk["h_inf"][hlo:hhi])
         pL, fL = oracle.msm("g1", l_pad[lo:hi], zc[lo:hi], l_inf[lo:hi])
         pA, fA = oracle.msm("g1", pk["a_query"][lo:hi], zc[lo:hi], pk["a_inf"][lo:hi])
         pB1, fB1 = oracle.msm("g1", pk["b_g1_query"][lo:hi], zc[lo:hi], pk["b_g1_inf"][lo:hi])
         pB2, fB2 = oracle.msm("g2", pk["b_g2_query"][lo:hi], zc[lo:hi], pk["b_g2_inf"][lo:hi])
-        if k == 0:
+        if blind:
             d1r, f = oracle.point_mul("g1", pk["delta_g1"], rc)
             pA, fA = oracle.point_add("g1", pA, d1r, fA, f)
             d1s, f = oracle.point_mul("g1", pk["delta_g1"], sc)
@@ -127,17 +132,62 @@ def test_combine_partials_matches_oracle(oracle, n_shards):
     assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
 
 
+@pytest.mark.parametrize("ranks,m,nh", [(1, 100, 127), (2, 150, 255), (8, 150, 255), (8, 8675317, (1 << 24) - 1), (4, 443893, (1 << 19) - 1),
+                                         (8, 5, 1023), (3, 1, 1), (5, 1000, 0)])
+def test_shard_plan_partitions_every_range(ranks, m, nh):
+    """zkg16_shard_plan (host-only): the z ranges and the h ranges each partition their index space exactly, exactly one rank
+    carries the blinding terms and that rank has z work, h ranges live on the first k ranks only, and forcing k is honoured."""
+    from zksnark_finalproject_amd.device import shard_plan
+    for force in (0, 1, ranks):
+        plan, k = shard_plan(ranks, m, nh, 0.0, force)
+        assert len(plan) == ranks and 1 <= k <= ranks and (force == 0 or k == force)
+        pos = 0
+        for z_lo, z_hi, _, _, _ in plan:
+            assert z_lo == pos and z_hi >= z_lo
+            pos = z_hi
+        assert pos == m
+        pos = 0
+        for i, (_, _, h_lo, h_hi, _) in enumerate(plan):
+            if i < k:
+                assert h_lo == pos and h_hi >= h_lo
+                pos = h_hi
+            else:
+                assert h_lo == h_hi == 0
+        assert pos == nh
+        blind = [p for p in plan if p[4]]
+        assert len(blind) == 1 and blind[0][1] > blind[0][0]
+    if ranks == 8 and m > 1000000:          # the headline config: the model must not fall back to "every rank repeats the witness map"
+        plan, k = shard_plan(ranks, m, nh)
+        assert k < ranks
+        z_sizes = [p[1] - p[0] for p in plan]
+        assert max(z_sizes[k:]) > max(z_sizes[:k])      # witness-map ranks take less z work
+
+
+def test_combine_partials_with_rank_roles(oracle):
+    """The role-based plan through the host finish: oracle-computed per-rank partials for zkg16_shard_plan's ranges == oracle proof."""
+    from zksnark_finalproject_amd.device import combine_partials, shard_plan
+    r1cs, z, pk, r, s = _case(oracle)
+    for ranks, force in ((4, 0), (4, 1), (3, 2)):
+        plan, k = shard_plan(ranks, z.shape[0], pk["h_query"].shape[0], 0.0, force)
+        parts, infs = _shard_partials(oracle, pk, r1cs, z, r, s, ranks, plan)
+        proof, inf = combine_partials(pk["alpha_g1"], pk["beta_g1"], pk["beta_g2"], fr_mont(r), fr_mont(s), np.array(parts), np.array(infs))
+        eproof, einf = oracle.prove(pk, fr_mont(r), fr_mont(s), r1cs, z)
+        assert np.array_equal(proof, eproof) and np.array_equal(inf, einf), (ranks, force)
+
+
 _WORKER = r'''
 import os, sys
 sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/tests/golden", ROOT + "/oracle"]
 import numpy as np, torch, torch.distributed as dist
 import oracle, test_abi_and_host as T
 from helpers import fr_mont
-from zksnark_finalproject_amd.device import combine_partials
+from zksnark_finalproject_amd.device import combine_partials, shard_plan
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 r1cs, z, pk, r, s = T._case(oracle)                      # same seed on every rank
-parts, infs = T._shard_partials(oracle, pk, r1cs, z, r, s, world)
+plan, k = shard_plan(world, z.shape[0], pk["h_query"].shape[0], 0.0, 1)    # rank roles: rank 0 runs the witness map, rank 1 has no h range
+assert k == 1 and plan[1][2] == plan[1][3]
+parts, infs = T._shard_partials(oracle, pk, r1cs, z, r, s, world, plan)
 rec = torch.from_numpy(np.concatenate([parts[rank].view(np.int64), infs[rank].astype(np.int64)]))   # this rank's 77-word record
 bufs = [torch.empty(77, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(bufs, rec)                               # the single exchange of the multi-GPU path
@@ -195,3 +245,11 @@ def test_host_only_entry_points_without_a_device():
     assert fn(None, None, None, None, 1, 0, C.addressof(ok)) == 1          # ZKG16_ERR_BAD_ARG
     assert fn(None, None, None, None, 0, 0, None) == 1
     assert fn(None, None, None, None, 0, 0, C.addressof(ok)) == 0 and ok.value == 1     # empty product
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py --gpus N under a launcher with another WORLD_SIZE exits non-zero before touching torch or the GPU, so a 1-rank
+    run can never be reported as N GPUs (round-1 finding: --gpus was parsed and never read)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "refusing" in out.stderr

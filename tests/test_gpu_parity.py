@@ -1,5 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C ABI, libzkg16.so) against the CPU oracle and the
 golden fixtures, bit-exact (all arithmetic is modular integer arithmetic; outputs are canonical)."""
+import os
 import random
 
 import numpy as np
@@ -269,7 +270,8 @@ def test_prove_random_vs_oracle_and_exponent(dev, oracle):
     assert np.array_equal(proof2, proof) and np.array_equal(inf2, inf)
     # every scheduling / tuning option leaves the proof bit-identical (the measured alternatives)
     for opt, vals in (("reduce_mode", (1, 0)), ("fixup_aux", (1, 0)), ("g1_waves", (1, 3, 4, 0)), ("window_bits_h", (9, 0)),
-                      ("window_bits", (7, 11, 0)), ("reduce_chunk", (4, 16, 0)), ("wm_concurrent", (0, -1))):
+                      ("window_bits", (7, 11, 0)), ("reduce_chunk", (4, 16, 0)), ("wm_concurrent", (0, -1)), ("fuse_pointwise", (0, 1)),
+                      ("ntt_mode", (0, 1))):
         for v in vals:
             dev.set_option(opt, v)
             p3, i3 = dev.prove_resident(ph, rh, wh, fr_mont(r), fr_mont(s))
@@ -334,8 +336,59 @@ def test_full_size_request_verifies(dev, n):
     assert handlers.verify_proof(res["vk"], bad, res["proof"])["valid"] is False
 
 
+@pytest.mark.parametrize("ranks,h_ranks", [(2, 0), (4, 0), (4, 1), (8, 0), (8, 8), (3, 2)])
+def test_rank_roles_partial_finish_equals_single_proof(dev, oracle, ranks, h_ranks):
+    """Multi-GPU rank roles on one device: the plan of zkg16_shard_plan (some ranks run the witness map and share h_query, every
+    rank takes a cost-weighted share of the z ranges), each rank's shard cut out of the resident key (zkg16_pk_slice) or loaded from
+    the host by range (zkg16_pk_load_range), partial per rank -> finish == the single-GPU proof == the oracle's proof."""
+    from zksnark_finalproject_amd.device import shard_plan
+    rng = random.Random(4242 + ranks)
+    nc, ni, nv = 5000, 3, 4100
+    A, B, C, z = synth.random_r1cs(rng, nc, ni, nv)
+    r1cs = synth.r1cs_arrays(A, B, C, ni)
+    pk, _ = synth.make_pk(oracle, r1cs, nv, rng, point_gen=dev.fixed_base)
+    zm = fr_mont_vec(z)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    ph, rh, wh = dev.pk_load(pk, ni), dev.r1cs_load(r1cs, nv), dev.witness_load(zm)
+    proof, inf = dev.prove_resident(ph, rh, wh, r, s)
+    eproof, einf = oracle.prove(pk, r, s, r1cs, zm)
+    assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
+    plan, k = shard_plan(ranks, nv, (1 << 13) - 1, 0.0, h_ranks)
+    assert 1 <= k <= ranks and (h_ranks == 0 or k == h_ranks)
+    assert sum(p[4] for p in plan) == 1
+    parts, pinf = [], []
+    for i, (z_lo, z_hi, h_lo, h_hi, blind) in enumerate(plan):
+        sh = dev.pk_slice(ph, z_lo, z_hi, h_lo, h_hi, blind) if i % 2 == 0 else dev.pk_load_range(pk, ni, z_lo, z_hi, h_lo, h_hi, blind)
+        p, f = dev.prove_partial(sh, rh, wh, r, s)
+        if h_hi == h_lo:
+            assert f[0] == 1            # no h range: this rank skipped the witness map and the H MSM
+        parts.append(p)
+        pinf.append(f)
+        dev.pk_free(sh)
+    proof2, inf2 = dev.prove_finish(ph, r, s, np.array(parts), np.array(pinf))
+    assert np.array_equal(proof2, proof) and np.array_equal(inf2, inf)
+    for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(hnd)
+
+
 def test_error_paths(dev):
     from zksnark_finalproject_amd import Zkg16Error
+    # malformed CSR row pointers are rejected on the host (the SpMV kernel walks them unchecked)
+    rng = random.Random(5)
+    A, B, C, z = synth.random_r1cs(rng, 20, 2, 12)
+    good = synth.r1cs_arrays(A, B, C, 2)
+    for mut in ("nonzero_start", "decreasing"):
+        bad = dict(good)
+        rp, col, cf = good["a"]
+        rp = rp.copy()
+        if mut == "nonzero_start":
+            rp[0] = 1
+        else:
+            rp[5], rp[6] = rp[6] + 1, rp[5]
+        bad["a"] = (rp, col, cf)
+        with pytest.raises(Zkg16Error) as e:
+            dev.r1cs_load(bad, 12)
+        assert e.value.status == 1   # ZKG16_ERR_BAD_ARG
     with pytest.raises(Zkg16Error) as e:
         dev.prove_resident(12345, 1, 2, fr_mont(1), fr_mont(2))
     assert e.value.status == 6       # ZKG16_ERR_BAD_HANDLE
@@ -345,11 +398,15 @@ def test_error_paths(dev):
     assert e.value.status == 2       # domain too large
 
 
-@pytest.mark.parametrize("kind", ["fib0", "fib10", "fib186", "matrix3", "matrix8"])
+@pytest.mark.parametrize("kind", ["fib0", "fib10", "fib186", "fib1000", "matrix3", "matrix8", "matrix32"])
 def test_prove_reference_circuits(dev, oracle, kind):
     """The reference's own circuits (C++ mirrors, csrc/circuits.hip) proved on the GPU: bit-identical to the oracle's proof
-    and satisfying the Groth16 equation in the exponent (known-trapdoor key)."""
+    and satisfying the Groth16 equation in the exponent (known-trapdoor key).  fib1000 = BASELINE configs[0] literally (the C++
+    mirror computes the result in Fr, so the public input matches the circuit where the reference's u128 wraps: SURVEY F8);
+    matrix32 = configs[1] at full size: 472,564 constraints, domain 2^19, oracle on all host threads."""
     from zksnark_finalproject_amd.circuits import fibonacci_circuit, matrix_circuit
+    if kind == "matrix32":
+        oracle.set_threads(min(os.cpu_count() or 1, 16))
     rng = random.Random(hash(kind) & 0xffff)
     if kind.startswith("fib"):
         c = fibonacci_circuit(0, 1, int(kind[3:]))                      # bench/fibo.py:26-34: a=0, b=1, rounds <= 186

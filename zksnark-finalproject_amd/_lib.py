@@ -28,6 +28,10 @@ SIGNATURES = {
     "zkg16_version": (C.c_char_p, []),
     "zkg16_pk_load": (C.c_int, [ctxp, u64p, vp, sz, u64p, vp, sz, u64p, vp, sz, vp, vp, sz, vp, vp, sz,
                                 u64p, u64p, u64p, u64p, u64p, sz, C.c_int, C.c_int, C.POINTER(H)]),
+    "zkg16_pk_load_range": (C.c_int, [ctxp, u64p, vp, sz, u64p, vp, sz, u64p, vp, sz, vp, vp, sz, vp, vp, sz,
+                                      u64p, u64p, u64p, u64p, u64p, sz, sz, sz, sz, sz, C.c_int, C.POINTER(H)]),
+    "zkg16_pk_slice": (C.c_int, [ctxp, H, sz, sz, sz, sz, C.c_int, C.POINTER(H)]),
+    "zkg16_shard_plan": (C.c_int, [C.c_int, sz, sz, C.c_double, C.c_int, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_pk_free": (None, [ctxp, H]),
     "zkg16_r1cs_load": (C.c_int, [ctxp] + [u64p, vp, vp] * 3 + [sz, sz, sz, C.POINTER(H)]),
     "zkg16_r1cs_free": (None, [ctxp, H]),
@@ -59,6 +63,7 @@ SIGNATURES = {
     "zkg16_fixed_base_g1": (C.c_int, [ctxp, u64p, vp, sz, vp, vp]),
     "zkg16_fixed_base_g2": (C.c_int, [ctxp, u64p, vp, sz, vp, vp]),
     "zkg16_bench_ntt": (C.c_int, [ctxp, sz, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "zkg16_bench_witness_map": (C.c_int, [ctxp, H, H, C.c_int, C.POINTER(C.c_float)]),
     "zkg16_bench_msm": (C.c_int, [ctxp, C.c_int, vp, vp, vp, sz, C.c_int, C.POINTER(C.c_float), u64p, u8p]),
     "zkg16_last_timings": (C.c_int, [ctxp, C.POINTER(C.c_float), C.c_int]),
     "zkg16_kernel_timing": (C.c_int, [ctxp, C.c_int]),

@@ -220,47 +220,54 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// The device part of a proof: witness map + the five MSMs over this ctx's pk shard.
+// events of one proof, destroyed on every exit path
+struct EventSet {
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    EventSet() { for (auto &e : ev) ZK_HIP(hipEventCreate(&e)); }
+    ~EventSet() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+    EventSet(const EventSet &) = delete;
+    EventSet &operator=(const EventSet &) = delete;
+};
+
+// The device part of a proof: witness map + the five MSMs over this ctx's pk shard.  A shard is a pair of index ranges:
+// [z_lo, z_hi) of the a / b_g1 / b_g2 / l queries and [h_lo, h_hi) of h_query.  A rank whose h range is empty skips the
+// witness map and the H MSM altogether, one whose z range is empty (and which does not carry the r, s, -rs terms) skips the
+// four z-side MSMs — this is what lets the ranks of a multi-GPU proof take different roles (zkg16_shard_plan).
 void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const Fr &r, const Fr &s, Partials &out,
                   const std::function<void()> *before_witness_map = nullptr) {
     const size_t m_total = rc.num_variables;
     if (wit.n != m_total || pk.m_total != m_total) throw HipError{hipErrorInvalidValue, "prove: assignment / key length mismatch", __FILE__, __LINE__};
     const size_t N = (size_t)1 << rc.log_n;
     if (pk.n_h_total != N - 1) throw HipError{hipErrorInvalidValue, "prove: h_query length != N-1", __FILE__, __LINE__};
-    hipEvent_t ev[5];                     // 0-1: z-side sort (main stream), 2-4: witness map / h-side sort (aux stream)
-    for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
+    EventSet evs;                         // 0-1: z-side sort (main stream), 2-4: witness map / h-side sort (aux stream)
+    hipEvent_t *ev = evs.ev;
     const double t0 = now_ms();
 
-    // ---- main stream: the z-side scalar vector (z-slice || r, s, -rs) -> canonical -> digits -> sort.  It does not depend
-    // on the witness map, so the G2 accumulation can start while h is still being computed on the aux stream.
+    // ---- main stream: the z-side scalar vector (z-slice || r, s, -rs), read in place by the digit kernel -> digits -> sort.
+    // It does not depend on the witness map, so the G2 accumulation can start while h is still being computed on the aux stream.
     const size_t nz = pk.z_hi - pk.z_lo;
     const size_t nzs = nz + 3;                                 // + r, s, -rs slots
     const size_t nh = pk.h_hi - pk.h_lo;
-    ctx->ws_z.scalars.ensure(nzs * sizeof(Fr));
-    ctx->ws_z.stage.ensure(nzs * sizeof(Fr));
-    ctx->ws_h.scalars.ensure((nh ? nh : 1) * sizeof(Fr));
-    for (int i = 0; i < 4; i++) ctx->poly[i].ensure(N * sizeof(Fr));
-    Fr *zs = ctx->ws_z.scalars.as<Fr>();
-    Fr *hs = ctx->ws_h.scalars.as<Fr>();
+    const bool z_side = nz > 0 || pk.blinding;
     MsmPlan plan_z, plan_h, plan_zb;
     const bool b_sparse = pk.b_skipped * 20 > nzs;             // > 5 % of the terms: worth a second (0.3 ms) sort
+    out.h = out.l = out.a = out.b1 = G1XYZZ::inf();
+    out.b2 = G2XYZZ::inf();
     ZK_HIP(hipEventRecord(ev[0], ctx->stream));
-    {
+    if (z_side) {
         if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
         Fr *extra = reinterpret_cast<Fr *>(ctx->extra_host);
-        const bool first = pk.shard_index == 0;               // the r/s/-rs terms are added by shard 0 only
-        extra[0] = first ? r : Fr::zero();
-        extra[1] = first ? s : Fr::zero();
-        extra[2] = first ? fp_neg(fp_mul(r, s)) : Fr::zero();
+        extra[0] = pk.blinding ? r : Fr::zero();              // the r/s/-rs terms are added by one shard only
+        extra[1] = pk.blinding ? s : Fr::zero();
+        extra[2] = pk.blinding ? fp_neg(fp_mul(r, s)) : Fr::zero();
+        ctx->ws_z.stage.ensure(3 * sizeof(Fr));
         Fr *stage = ctx->ws_z.stage.as<Fr>();
-        if (nz) ZK_HIP(hipMemcpyAsync(stage, wit.z.as<Fr>() + pk.z_lo, nz * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(stage + nz, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));   // pinned; reused only after this proof
-        fr_from_mont_run(ctx, stage, zs, nzs);
-        msm_plan_build(ctx, ctx->ws_z, zs, nzs, plan_z);
+        ZK_HIP(hipMemcpyAsync(stage, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));   // pinned; reused only after this proof
+        ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, stage, 3, true, nullptr};
+        msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z);
         if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
-            ctx->ws_zb.scalars.ensure(nzs * sizeof(Fr));
-            mask_scalars_run(ctx, zs, pk.b_mask.as<uint8_t>(), ctx->ws_zb.scalars.as<Fr>(), nzs);
-            msm_plan_build(ctx, ctx->ws_zb, ctx->ws_zb.scalars.as<Fr>(), nzs, plan_zb);
+            zsrc.mask = pk.b_mask.as<uint8_t>();
+            msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb);
         }
     }
     ZK_HIP(hipEventRecord(ev[1], ctx->stream));
@@ -272,10 +279,12 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // reduction then hides behind the G1 accumulations); their reductions — whose first packet is a wait — only after those
     // launches (msm_enqueue_reduce).  Kernel trace at n = 32: queued after the witness map, the G2 accumulation started
     // 2.0 ms into the proof with its inputs ready at 0.6 ms.
-    msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
-    msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
-    msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
-    msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    if (z_side) {
+        msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
+        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
+        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
+        msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+    }
 
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
     // z-side work (measured in one process, n = 32: 18.15 vs 18.58 ms in order; n = 12: 10.05 vs 11.16 ms)
@@ -287,10 +296,12 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         if (before_witness_map) (*before_witness_map)();
         ZK_HIP(hipEventRecord(ev[2], ctx->stream));
         Fr *h = nullptr;
-        witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
+        if (nh) witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
         ZK_HIP(hipEventRecord(ev[3], ctx->stream));
-        if (nh) fr_from_mont_run(ctx, h + pk.h_lo, hs, nh);
-        msm_plan_build(ctx, ctx->ws_h, hs, nh, plan_h, ctx->opt_window_bits_h);
+        if (nh) {
+            const ScalarSrc hsrc{h + pk.h_lo, nh, nullptr, 0, true, nullptr};
+            msm_plan_build(ctx, ctx->ws_h, hsrc, plan_h, ctx->opt_window_bits_h);
+        }
         ZK_HIP(hipEventRecord(ev[4], ctx->stream));
     } catch (...) {
         if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
@@ -298,41 +309,48 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     }
     if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
 
-    msm_g2_enqueue_reduce(ctx, ctx->slots[0]);
-    msm_g1_enqueue_reduce(ctx, ctx->slots[2]);
-    msm_g1_enqueue_reduce(ctx, ctx->slots[3]);
-    msm_g1_enqueue_reduce(ctx, ctx->slots[4]);
+    if (z_side) {
+        msm_g2_enqueue_reduce(ctx, ctx->slots[0]);
+        msm_g1_enqueue_reduce(ctx, ctx->slots[2]);
+        msm_g1_enqueue_reduce(ctx, ctx->slots[3]);
+        msm_g1_enqueue_reduce(ctx, ctx->slots[4]);
+    }
     if (trace) fprintf(stderr, "host: z-side msms queued at %.3f ms\n", now_ms() - t0);
 
     // ---- H last: it is the only MSM that waits for the witness map; then collect — each MSM's host Horner overlaps the
     // device work still queued behind it
-    if (trace) fprintf(stderr, "host: witness map queued at %.3f ms\n", now_ms() - t0);
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
-    msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
+    if (nh) msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
     if (trace) fprintf(stderr, "host: h queued at %.3f ms\n", now_ms() - t0);
     double tprev = now_ms();
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
-    out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
-    out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
-    out.a = msm_g1_collect(ctx, ctx->slots[3]);
-    const bool early = pk.shard_count == 1;
-    if (early) {
-        G1XYZZ A = out.a;
-        xyzz_madd(A, pk.alpha_g1, false);
-        const Fr sc = fp_from_mont(s);
-        out.s_a = xyzz_mul(A, sc.l);
+    const bool early = pk.full;
+    if (z_side) {
+        out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
+        out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
+        out.a = msm_g1_collect(ctx, ctx->slots[3]);
+        if (early) {
+            G1XYZZ A = out.a;
+            xyzz_madd(A, pk.alpha_g1, false);
+            const Fr sc = fp_from_mont(s);
+            out.s_a = xyzz_mul(A, sc.l);
+        }
+        lap(5);
+        out.b1 = msm_g1_collect(ctx, ctx->slots[4]);
+        if (early) {
+            G1XYZZ B1 = out.b1;
+            xyzz_madd(B1, pk.beta_g1, false);
+            const Fr rc_ = fp_from_mont(r);
+            out.r_b1 = xyzz_mul(B1, rc_.l);
+            out.have_early = true;
+        }
+        lap(6);
+    } else {
+        ctx->timings[4] = ctx->timings[5] = ctx->timings[6] = ctx->timings[7] = 0;
     }
-    lap(5);
-    out.b1 = msm_g1_collect(ctx, ctx->slots[4]);
-    if (early) {
-        G1XYZZ B1 = out.b1;
-        xyzz_madd(B1, pk.beta_g1, false);
-        const Fr rc_ = fp_from_mont(r);
-        out.r_b1 = xyzz_mul(B1, rc_.l);
-        out.have_early = true;
-    }
-    lap(6);
-    out.h = msm_g1_collect(ctx, ctx->slots[1]); lap(3);
+    if (nh) out.h = msm_g1_collect(ctx, ctx->slots[1]);
+    else ZK_HIP(hipStreamSynchronize(ctx->stream));
+    lap(3);
     float ms;
     // [1] witness map, [2] digits+sort of both vectors (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2
     // (collected in the order B2, L, A, B1, H — the first gap contains most of the device time)
@@ -344,7 +362,6 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     ZK_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
     ctx->timings[2] += ms;
     ctx->timings[9] = (float)(now_ms() - t0);
-    for (auto &e : ev) (void)hipEventDestroy(e);
 }
 
 // Host tail (a9): A = alpha + MSM_a, B = beta + MSM_b, C = s*A + r*B1 + MSM_l + MSM_h.
@@ -403,6 +420,10 @@ int r1cs_create(const uint64_t *const rp[3], const uint32_t *const col[3], const
     r->log_n = log_n;
     for (int i = 0; i < 3; i++) {
         const size_t nnz = rp[i][num_constraints];
+        // row pointers: start at 0, never decrease, end at nnz — spmv_kernel walks [rp[row], rp[row+1]) unchecked on the device
+        if (rp[i][0] != 0) return ZKG16_ERR_BAD_ARG;
+        for (size_t row = 0; row < num_constraints; row++)
+            if (rp[i][row] > rp[i][row + 1]) return ZKG16_ERR_BAD_ARG;
         uint32_t top = 0;
         for (size_t k = 0; k < nnz; k++) top = col[i][k] > top ? col[i][k] : top;
         if (nnz && top >= num_variables) return ZKG16_ERR_BAD_ARG;
@@ -492,6 +513,12 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
         hipDeviceProp_t prop;
         ZK_HIP(hipGetDeviceProperties(&prop, dev));
         ctx->num_cus = prop.multiProcessorCount;
+        // the code object holds gfx950 kernels only (no fallback path, no other ISA): any other device is "no device"
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            ctx->last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+            delete ctx;
+            return ZKG16_ERR_NO_DEVICE;
+        }
         // Plain (equal-priority) streams.  Measured at n = 32: main low / witness-map high priority 16.6 ms per proof,
         // reversed 16.2 ms, no priorities 15.0 ms (profiles/kernel_timeline_r1_*.txt).
         ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -581,6 +608,10 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_wm_concurrent = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "fuse_pointwise")) {     // 1 (default): (ab - c)/Z on the load of the seventh transform; 0: own pass
+        ctx->opt_fuse_pointwise = value ? 1 : 0;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "reduce_chunk")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return ZKG16_ERR_BAD_ARG;
         ctx->opt_reduce_chunk = (int)value;
@@ -589,31 +620,28 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     return ZKG16_ERR_UNSUPPORTED;
 }
 
-int zkg16_pk_load(zkg16_ctx *ctx,
-                  const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
-                  const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
-                  const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
-                  const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
-                  const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
-                  const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
-                  const uint64_t delta_g1[12], const uint64_t delta_g2[24],
-                  size_t num_instance, int shard_index, int shard_count, uint64_t *pk_handle) {
+int zkg16_pk_load_range(zkg16_ctx *ctx,
+                        const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
+                        const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
+                        const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
+                        const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
+                        const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
+                        const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                        const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                        size_t num_instance, size_t z_lo, size_t z_hi, size_t h_lo, size_t h_hi, int blinding, uint64_t *pk_handle) {
     if (!pk_handle || !a_query || !b_g1_query || !b_g2_query || (!h_query && n_h) || (!l_query && n_l) || !alpha_g1 || !beta_g1 ||
         !beta_g2 || !delta_g1 || !delta_g2)
         return ZKG16_ERR_BAD_ARG;
     if (n_a == 0 || n_a != n_b1 || n_a != n_b2 || num_instance == 0 || num_instance > n_a || n_l != n_a - num_instance) return ZKG16_ERR_BAD_ARG;
-    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return ZKG16_ERR_BAD_ARG;
+    if (z_lo > z_hi || z_hi > n_a || h_lo > h_hi || h_hi > n_h) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
     auto pk = std::make_unique<PkDev>();
     pk->num_instance = num_instance;
     pk->m_total = n_a;
     pk->n_h_total = n_h;
-    pk->shard_index = shard_index;
-    pk->shard_count = shard_count;
-    pk->z_lo = n_a * (size_t)shard_index / shard_count;
-    pk->z_hi = n_a * (size_t)(shard_index + 1) / shard_count;
-    pk->h_lo = n_h * (size_t)shard_index / shard_count;
-    pk->h_hi = n_h * (size_t)(shard_index + 1) / shard_count;
+    pk->z_lo = z_lo; pk->z_hi = z_hi; pk->h_lo = h_lo; pk->h_hi = h_hi;
+    pk->blinding = blinding != 0;
+    pk->full = z_lo == 0 && z_hi == n_a && h_lo == 0 && h_hi == n_h && pk->blinding;
     const size_t nz = pk->z_hi - pk->z_lo, nh = pk->h_hi - pk->h_lo;
     pk->a.alloc((nz + 3) * sizeof(G1AffineU));
     pk->b1.alloc((nz + 3) * sizeof(G1AffineU));
@@ -650,6 +678,123 @@ int zkg16_pk_load(zkg16_ctx *ctx,
     *pk_handle = ctx->next_handle++;
     ctx->pks[*pk_handle] = std::move(pk);
     ZK_API_END(ctx)
+}
+
+int zkg16_pk_load(zkg16_ctx *ctx,
+                  const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
+                  const uint64_t *b_g1_query, const uint8_t *b_g1_inf, size_t n_b1,
+                  const uint64_t *b_g2_query, const uint8_t *b_g2_inf, size_t n_b2,
+                  const uint64_t *h_query, const uint8_t *h_inf, size_t n_h,
+                  const uint64_t *l_query, const uint8_t *l_inf, size_t n_l,
+                  const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                  const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                  size_t num_instance, int shard_index, int shard_count, uint64_t *pk_handle) {
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return ZKG16_ERR_BAD_ARG;
+    return zkg16_pk_load_range(ctx, a_query, a_inf, n_a, b_g1_query, b_g1_inf, n_b1, b_g2_query, b_g2_inf, n_b2, h_query, h_inf, n_h, l_query,
+                               l_inf, n_l, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, num_instance,
+                               n_a * (size_t)shard_index / shard_count, n_a * (size_t)(shard_index + 1) / shard_count,
+                               n_h * (size_t)shard_index / shard_count, n_h * (size_t)(shard_index + 1) / shard_count, shard_index == 0,
+                               pk_handle);
+}
+
+// A shard of a key that is already resident (zkg16_setup_resident / an un-sharded zkg16_pk_load): device-to-device copies of
+// the index ranges, nothing crosses PCIe.
+int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t src_handle, size_t z_lo, size_t z_hi, size_t h_lo, size_t h_hi, int blinding,
+                   uint64_t *pk_handle) {
+    if (!pk_handle) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *src = find_handle(ctx->pks, src_handle);
+    if (!src) return ZKG16_ERR_BAD_HANDLE;
+    if (!src->full) return ZKG16_ERR_BAD_ARG;
+    if (z_lo > z_hi || z_hi > src->m_total || h_lo > h_hi || h_hi > src->n_h_total) return ZKG16_ERR_BAD_ARG;
+    auto pk = std::make_unique<PkDev>();
+    pk->num_instance = src->num_instance;
+    pk->m_total = src->m_total;
+    pk->n_h_total = src->n_h_total;
+    pk->z_lo = z_lo; pk->z_hi = z_hi; pk->h_lo = h_lo; pk->h_hi = h_hi;
+    pk->blinding = blinding != 0;
+    pk->full = z_lo == 0 && z_hi == src->m_total && h_lo == 0 && h_hi == src->n_h_total && pk->blinding;
+    const size_t nz = z_hi - z_lo, nh = h_hi - h_lo, sm = src->m_total;
+    pk->a.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->b1.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->l.alloc((nz + 3) * sizeof(G1AffineU));
+    pk->b2.alloc((nz + 3) * sizeof(G2AffineU));
+    pk->h.alloc((nh ? nh : 1) * sizeof(G1AffineU));
+    auto cp = [&](DevBuf &dst, const DevBuf &from, size_t elem) {
+        if (nz) ZK_HIP(hipMemcpyAsync(dst.p, static_cast<const unsigned char *>(from.p) + z_lo * elem, nz * elem, hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(static_cast<unsigned char *>(dst.p) + nz * elem, static_cast<const unsigned char *>(from.p) + sm * elem, 3 * elem,
+                              hipMemcpyDeviceToDevice, ctx->stream));      // the three trailing delta slots
+    };
+    cp(pk->a, src->a, sizeof(G1AffineU));
+    cp(pk->b1, src->b1, sizeof(G1AffineU));
+    cp(pk->l, src->l, sizeof(G1AffineU));
+    cp(pk->b2, src->b2, sizeof(G2AffineU));
+    if (nh) ZK_HIP(hipMemcpyAsync(pk->h.p, src->h.as<G1AffineU>() + h_lo, nh * sizeof(G1AffineU), hipMemcpyDeviceToDevice, ctx->stream));
+    pk->alpha_g1 = src->alpha_g1; pk->beta_g1 = src->beta_g1; pk->delta_g1 = src->delta_g1;
+    pk->beta_g2 = src->beta_g2; pk->delta_g2 = src->delta_g2;
+    pk->b_mask.alloc(nz + 3);
+    pk->b_skipped = b_density_mask_run(ctx, pk->b1.as<G1AffineU>(), pk->b2.as<G2AffineU>(), nz + 3, pk->b_mask.as<uint8_t>());
+    *pk_handle = ctx->next_handle++;
+    ctx->pks[*pk_handle] = std::move(pk);
+    ZK_API_END(ctx)
+}
+
+// Rank roles for one proof over n_ranks GPUs (host-only, no ctx).  Work is counted in G1 mixed additions: a z-side term
+// costs W_z * (2 + density * (1 + kappa)) (L, A, and the B1 / B2 terms that are not infinity; kappa = G2 : G1 addition cost),
+// an h term W_h, the witness map omega per domain element.  The first k ranks run the witness map and share h_query; every
+// rank takes a share of the z ranges proportional to the time it has left, so that all finish together at
+//   T(k) = max( (Z + H + k * WM) / n_ranks,  WM + H / k ),
+// and k is the one that minimises T (k = n_ranks is the homogeneous split of round 1: every rank repeats the witness map).
+static int default_window_bits(size_t n) {
+    if (n >= ((size_t)1 << 20)) return 16;
+    if (n >= ((size_t)1 << 17)) return 15;
+    if (n >= ((size_t)1 << 14)) return 13;
+    int lg = 0;
+    while (((size_t)2 << lg) <= n) lg++;
+    return lg - 3 < 4 ? 4 : lg - 3;
+}
+int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, uint64_t *ranges, uint8_t *blinding,
+                     int *h_ranks_out) {
+    if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
+    if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
+    constexpr double KAPPA = 2.8, OMEGA = 12.0;
+    const int G = n_ranks;
+    const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
+    const double Z = (double)m_total * Wz * (2.0 + b_density * (1.0 + KAPPA)), H = (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
+    auto T_of = [&](int k) { const double a = (Z + H + k * WM) / G, b = WM + H / k; return a > b ? a : b; };
+    int k = h_ranks;
+    if (k == 0) {
+        k = 1;
+        for (int c = 2; c <= G; c++)
+            if (T_of(c) < T_of(k) * (1.0 - 1e-9)) k = c;
+    }
+    const double T = T_of(k);
+    std::vector<double> cap(G);
+    double cap_sum = 0;
+    for (int i = 0; i < G; i++) {
+        cap[i] = i < k ? T - WM - H / k : T;
+        if (cap[i] < 0) cap[i] = 0;
+        cap_sum += cap[i];
+    }
+    if (!(cap_sum > 0)) { cap.assign(G, 1.0); cap_sum = G; }
+    double acc = 0;
+    size_t prev = 0;
+    bool blind_given = false;
+    for (int i = 0; i < G; i++) {
+        acc += cap[i];
+        size_t hi = i == G - 1 ? m_total : (size_t)((double)m_total * (acc / cap_sum) + 0.5);
+        if (hi < prev) hi = prev;
+        if (hi > m_total) hi = m_total;
+        ranges[4 * i + 0] = prev;
+        ranges[4 * i + 1] = hi;
+        ranges[4 * i + 2] = i < k ? n_h * (size_t)i / k : 0;
+        ranges[4 * i + 3] = i < k ? n_h * (size_t)(i + 1) / k : 0;
+        blinding[i] = (!blind_given && hi > prev) ? 1 : 0;
+        blind_given = blind_given || blinding[i];
+        prev = hi;
+    }
+    if (h_ranks_out) *h_ranks_out = k;
+    return ZKG16_OK;
 }
 
 void zkg16_pk_free(zkg16_ctx *ctx, uint64_t h) {
@@ -753,7 +898,7 @@ int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handl
     R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
     WitnessDev *wit = find_handle(ctx->wits, witness_handle);
     if (!pk || !rc || !wit) return ZKG16_ERR_BAD_HANDLE;
-    if (pk->shard_count != 1) return ZKG16_ERR_BAD_ARG;                 // sharded keys go through prove_partial/finish
+    if (!pk->full) return ZKG16_ERR_BAD_ARG;                            // sharded keys go through prove_partial/finish
     if (wit->n != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != rc->num_instance ||
         pk->n_h_total != ((size_t)1 << rc->log_n) - 1)
         return ZKG16_ERR_BAD_ARG;
@@ -777,7 +922,7 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
     ZK_API_BEGIN(ctx)
     PkDev *pk = find_handle(ctx->pks, pk_handle);
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
-    if (pk->shard_count != 1) return ZKG16_ERR_BAD_ARG;
+    if (!pk->full) return ZKG16_ERR_BAD_ARG;
     const uint64_t *rp[3] = {a_row_ptr, b_row_ptr, c_row_ptr};
     const uint32_t *col[3] = {a_col, b_col, c_col};
     const uint64_t *cf[3] = {a_coeff, b_coeff, c_coeff};
@@ -853,8 +998,8 @@ int zkg16_ntt(zkg16_ctx *ctx, uint64_t *data, size_t log_n, int inverse, int cos
     const size_t n = (size_t)1 << log_n;
     DevBuf d(n * sizeof(Fr)), t(n * sizeof(Fr));
     ZK_HIP(hipMemcpyAsync(d.p, data, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
-    ZK_HIP(hipMemcpyAsync(data, d.p, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    const Fr *res = ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    ZK_HIP(hipMemcpyAsync(data, res, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     ZK_API_END(ctx)
 }
@@ -872,7 +1017,10 @@ int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int it
     ZK_HIP(hipEventCreate(&e0));
     ZK_HIP(hipEventCreate(&e1));
     ZK_HIP(hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters; i++) ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    for (int i = 0; i < iters; i++) {      // ping-pong, as the witness map does
+        if (i & 1) ntt_run(ctx, t.as<Fr>(), d.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+        else ntt_run(ctx, d.as<Fr>(), t.as<Fr>(), (int)log_n, inverse != 0, coset != 0);
+    }
     ZK_HIP(hipEventRecord(e1, ctx->stream));
     ZK_HIP(hipEventSynchronize(e1));
     float ms = 0;
@@ -880,6 +1028,27 @@ int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int it
     *ms_per_iter = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    ZK_API_END(ctx)
+}
+
+// the whole R1CS -> QAP witness map (3 SpMV + 7 NTT + point-wise) alone on the device, repeated: stand-alone time per config
+int zkg16_bench_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, int iters, float *ms_per_iter) {
+    if (!ms_per_iter || iters < 1) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    if (!rc || !wit) return ZKG16_ERR_BAD_HANDLE;
+    if (wit->n != rc->num_variables) return ZKG16_ERR_BAD_ARG;
+    Fr *h = nullptr;
+    witness_map_run(ctx, *rc, wit->z.as<Fr>(), &h);
+    EventSet evs;
+    ZK_HIP(hipEventRecord(evs.ev[0], ctx->stream));
+    for (int i = 0; i < iters; i++) witness_map_run(ctx, *rc, wit->z.as<Fr>(), &h);
+    ZK_HIP(hipEventRecord(evs.ev[1], ctx->stream));
+    ZK_HIP(hipEventSynchronize(evs.ev[1]));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, evs.ev[0], evs.ev[1]));
+    *ms_per_iter = ms / iters;
     ZK_API_END(ctx)
 }
 

@@ -96,7 +96,8 @@ struct PkDev {              // proving key shard resident in HBM (affine AoS; (0
     size_t b_skipped = 0;                            // number of such terms (B-side plan is separate when this is worth a sort)
     G1Affine alpha_g1, beta_g1, delta_g1;            // host copies for the tail
     G2Affine beta_g2, delta_g2;
-    int shard_index = 0, shard_count = 1;
+    bool blinding = true;                            // this shard's MSMs carry the r*delta, s*delta, -rs*delta terms
+    bool full = true;                                // whole key (all ranges + blinding terms): zkg16_prove / _resident
 };
 
 struct R1csDev {
@@ -160,6 +161,7 @@ struct zkg16_ctx {
     int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
+    int opt_fuse_pointwise = 1;                       // (ab - c)/Z on the load of the seventh transform (0: its own pass)
     int num_cus = 256;
     bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
     zk::FixedBaseCache fb_g1, fb_g2;
@@ -183,7 +185,10 @@ struct ScopedKernelTimer {
 void kernel_timer_resolve(zkg16_ctx *ctx);
 
 // ---- entry points implemented per translation unit
-void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset);   // result left in `data`
+// Out of place: returns `dst`, which holds the transform of `src`; `src` is scratch afterwards.  pw: optional fused
+// point-wise stage on the input, src[i] <- (src[i] * b[i] - c[i]) * zinv (the witness map's (ab - c)/Z).
+struct NttPointwise { const Fr *b, *c; Fr zinv; };
+Fr *ntt_run(zkg16_ctx *ctx, Fr *src, Fr *dst, int log_n, bool inverse, bool coset, const NttPointwise *pw = nullptr);
 NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n);
 
 void spmv_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c);
@@ -200,6 +205,10 @@ struct MsmPlan {
     uint32_t lanes_g1 = 0, lanes_g2 = 0; // lanes of one resident round of accumulation waves (2 / 1 waves per SIMD)
 };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan, int window_bits = 0);
+// The scalar vector where it lives: n_main elements at `main` then n_extra at `extra`; `mont` = arkworks' Montgomery form
+// (converted inside the digit kernel); mask[i] != 0 zeroes scalar i (B-query density filter).  All device pointers.
+struct ScalarSrc { const Fr *main; size_t n_main; const Fr *extra; size_t n_extra; bool mont; const uint8_t *mask; };
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits = 0);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
 void radix_sort_hi32(zkg16_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, unsigned key_bits, DevBuf &temp, const char *timer_name);
 // setup.hip: Groth16 key generation from a known trapdoor (discrete logs on device, then fixed-base batches)
@@ -227,7 +236,6 @@ void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t
 void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n);
 
 size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask);
-void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out, size_t n);
 // device outputs; either may be null: saturated (arkworks layout, host-bound) and/or unsaturated (device-resident key)
 void fixed_base_g1_run(zkg16_ctx *ctx, const G1Affine &base, const Fr *scalars_canonical, size_t n, G1Affine *out_sat, G1AffineU *out_u = nullptr);
 void fixed_base_g2_run(zkg16_ctx *ctx, const G2Affine &base, const Fr *scalars_canonical, size_t n, G2Affine *out_sat, G2AffineU *out_u = nullptr);

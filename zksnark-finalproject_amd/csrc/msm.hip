@@ -51,14 +51,32 @@ __device__ __forceinline__ void stv(T *p, const T &v) {
 
 // ------------------------------------------------------------------------------------------------ scalar side
 // keys[w*n + i] = bucket id << 32 | i << 1 | neg, bucket id = w * 2^(c-1) + |d| - 1, or `invalid_bucket` (sorts last) for digit 0
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *scalars, size_t n, int c, int nwin, size_t nb,
-                                                         uint64_t *keys, uint32_t invalid_bucket) {
+// The scalar vector is read where it lives: n_main elements at `scalars` followed by n_extra at `extra` (the r, s, -rs
+// terms of a proof), in arkworks' Montgomery form when `mont` (the conversion `into_bigint()` of prover.rs is done here, in
+// registers — round 1 ran a separate fr_from_mont pass plus a staging copy per scalar vector), zeroed where mask[i] != 0
+// (terms whose base is infinity in both B queries: b_density_mask_kernel).
+struct DigitSrc {
+    const uint32_t *scalars, *extra;
+    size_t n_main, n;
+    const uint8_t *mask;
+    int mont;
+};
+__global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, int nwin, size_t nb, uint64_t *keys, uint32_t invalid_bucket) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = src.n;
     if (i >= n) return;
     uint32_t s[9];
-    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + 8 * i);
-    uint4 lo = q[0], hi = q[1];
-    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w; s[8] = 0;
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(i < src.n_main ? src.scalars + 8 * i : src.extra + 8 * (i - src.n_main));
+        uint4 lo = q[0], hi = q[1];
+        if (src.mask && src.mask[i]) lo = hi = make_uint4(0, 0, 0, 0);
+        Fr v;
+        v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w; v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+        if (src.mont) v = fp_from_mont(v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = v.l[k];
+        s[8] = 0;
+    }
     // scalars above (r-1)/2 are replaced by r - s with the sign of every digit flipped: the magnitude then fits 254
     // bits, so the top window never carries out and no carry-only window (one giant bucket) exists.
     constexpr uint32_t RH[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};  // (r-1)/2
@@ -428,16 +446,6 @@ __global__ void __launch_bounds__(256) b_density_mask_kernel(const G1AffineU *b1
     mask[i] = skip ? 1 : 0;
     if (skip) atomicAdd(count, 1u);
 }
-__global__ void __launch_bounds__(256) mask_scalars_kernel(const Fr *in, const uint8_t *mask, Fr *out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4 *q = reinterpret_cast<const uint4 *>(in + i);
-    uint4 a = q[0], b = q[1];
-    if (mask[i]) a = b = make_uint4(0, 0, 0, 0);
-    uint4 *o = reinterpret_cast<uint4 *>(out + i);
-    o[0] = a;
-    o[1] = b;
-}
 size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask) {
     DevBuf cnt(sizeof(uint32_t));
     ZK_HIP(hipMemsetAsync(cnt.p, 0, sizeof(uint32_t), ctx->stream));
@@ -447,11 +455,6 @@ size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *
     ZK_HIP(hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return h;
-}
-void mask_scalars_run(zkg16_ctx *ctx, const Fr *in, const uint8_t *mask, Fr *out, size_t n) {
-    if (!n) return;
-    hipLaunchKernelGGL(mask_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, mask, out, n);
-    ZK_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------ fixed base
@@ -565,6 +568,11 @@ static int pick_window_bits(zkg16_ctx *ctx, size_t n) {
 }
 
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan, int window_bits) {
+    const ScalarSrc src{scalars_canonical, n, nullptr, 0, false, nullptr};
+    msm_plan_build(ctx, ws, src, plan, window_bits);
+}
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits) {
+    const size_t n = src.n_main + src.n_extra;
     plan.n = n;
     plan.c = (window_bits >= 2 && window_bits <= 16) ? window_bits : pick_window_bits(ctx, n);
     plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
@@ -578,8 +586,9 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
     {
         ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const uint32_t *>(scalars_canonical), n, plan.c, plan.nwin, plan.nb,
+        const DigitSrc d{reinterpret_cast<const uint32_t *>(src.main), reinterpret_cast<const uint32_t *>(src.extra), src.n_main, n, src.mask,
+                         src.mont ? 1 : 0};
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin, plan.nb,
                            ws.keys.as<uint64_t>(), (uint32_t)tb);
     }
     unsigned key_bits = 1;
@@ -871,7 +880,11 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
     for (auto &x : cache.e)
         if (x.wbits == wbits && x.key.size() == sizeof base && memcmp(x.key.data(), &base, sizeof base) == 0) ent = &x;
     const bool miss = ent == nullptr;
-    if (miss) ent = cache.e[0].stamp <= cache.e[1].stamp ? &cache.e[0] : &cache.e[1];      // replace the older one
+    if (miss) {
+        ent = cache.e[0].stamp <= cache.e[1].stamp ? &cache.e[0] : &cache.e[1];      // replace the older one
+        ent->key.clear();              // the victim matches nothing while its table is rebuilt: a failed build (OOM at large
+        ent->wbits = 0;                // sizes) must not leave the old key attached to a half-built table
+    }
     ent->stamp = ++cache.clock;
     if (miss) {
         // the 32 window bases 2^(8w) * base as affine points, one host inversion for all of them

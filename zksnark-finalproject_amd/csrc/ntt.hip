@@ -60,6 +60,11 @@ struct NttPassArgs {
     const Fr *w;       // w_N^j table
     const uint32_t *wu; // the same table in the unsaturated form (9 x u32 per entry), only for the global-twiddle kernels
     const Fr *pre;     // optional per-input-index multiplier (coset fft), else null
+    // optional fused point-wise stage of the witness map on the FIRST pass's load (pre is null then):
+    //   x[i] <- (in[i] * pw_b[i] - pw_c[i]) / Z   — ark-groth16 r1cs_to_qap.rs: ab = (a*b - c) * Z(g)^-1 before the coset ifft
+    const Fr *pw_b, *pw_c;
+    Fr pw_zinv;        // saturated kernels: 1/Z (Montgomery)
+    FrU pw_zc;         // unsaturated kernels: 1/Z * 2^271 mod r, repacked (see load_u)
     const Fr *post;    // optional per-output-index multiplier (coset ifft), else null
     Fr post_const;     // used when post_const_on (plain ifft: N^-1)
     int post_const_on;
@@ -130,6 +135,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_cols(NttPassArgs a) {
         const size_t gi = (size_t)i1 * n2 + col0 + c;
         Fr v = gld(in + gi);
         if (a.pre) v = fp_mul(v, gld(a.pre + gi));
+        else if (a.pw_b) v = fp_mul(fp_sub(fp_mul(v, gld(a.pw_b + gi)), gld(a.pw_c + gi)), a.pw_zinv);
         lds_st(s_data, NTT_TILE, (c << a.log_n1) + i1, v);
     }
     __syncthreads();
@@ -168,6 +174,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_rows(NttPassArgs a) {
             const size_t gi = (row0 + r) * n2 + i2;
             v = gld(in + gi);
             if (a.pre) v = fp_mul(v, gld(a.pre + gi));
+            else if (a.pw_b) v = fp_mul(fp_sub(fp_mul(v, gld(a.pw_b + gi)), gld(a.pw_c + gi)), a.pw_zinv);
         }
         lds_st(s_data, NTT_TILE, t, v);
     }
@@ -255,10 +262,17 @@ __device__ __forceinline__ void stage_twiddles_u(uint32_t *s_tw, int tw_stride, 
     }
 }
 
-// element load: saturated -> U-form, times the optional per-index multiplier (coset fft)
-__device__ __forceinline__ FrU load_u(const Fr *in, const Fr *pre, size_t gi) {
+// element load: saturated -> U-form, times the optional per-index multiplier (coset fft), or the fused point-wise stage
+// (x * b - c) / Z: with X = x 2^256 etc. as stored,  X (*) B = xb 2^251,  C (*) 2^256 = c 2^251,  their difference (+2r) times
+// zc = 2^271 / Z gives (xb - c)/Z * 2^261, the U-form  ((*) = fru_mul = product * 2^-261; operands stay far below 70 r^2)
+__device__ __forceinline__ FrU load_u(const NttPassArgs &a, const Fr *in, size_t gi) {
     const FrU x = fru_repack(gld(in + gi));
-    if (pre) return fru_mul(x, fru_mul(fru_repack(gld(pre + gi)), fru_c271()));
+    if (a.pre) return fru_mul(x, fru_mul(fru_repack(gld(a.pre + gi)), fru_c271()));
+    if (a.pw_b) {
+        const FrU xb = fru_mul(x, fru_repack(gld(a.pw_b + gi)));
+        const FrU c = fru_mul(fru_repack(gld(a.pw_c + gi)), fru_one_sat());
+        return fru_mul(fru_sub_2r(xb, c), a.pw_zc);
+    }
     return fru_mul(x, fru_c266());
 }
 
@@ -281,7 +295,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int c = t & (C - 1), i1 = t >> log_c;
         const size_t gi = (size_t)i1 * n2 + col0 + c;
-        lds_st_u(s_data, TILE, (c << a.log_n1) + i1, load_u(in, a.pre, gi));
+        lds_st_u(s_data, TILE, (c << a.log_n1) + i1, load_u(a, in, gi));
     }
     __syncthreads();
     lds_dif_u<TL, GTW>(s_data, s_tw, a.log_n1, tw_stride, a);
@@ -315,7 +329,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) 
         FrU v;
 #pragma unroll
         for (int k = 0; k < 9; k++) v.l[k] = 0;
-        if (row0 + r < n1) v = load_u(in, a.pre, (row0 + r) * n2 + i2);
+        if (row0 + r < n1) v = load_u(a, in, (row0 + r) * n2 + i2);
         lds_st_u(s_data, TILE, t, v);
     }
     __syncthreads();
@@ -395,13 +409,19 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
     hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->g.as<Fr>(), g, Fr::one(), n);
     hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(bs), 0, ctx->stream, t->gi.as<Fr>(), g_inv, t->n_inv, n);
     ZK_HIP(hipGetLastError());
+    // built once per domain size on whichever stream is current; the ctx's other streams (witness map, setup's G2 pass) read
+    // the tables later without an event between them, so the build is completed here — and only cached once it has succeeded
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     NttTables *raw = t.get();
     ctx->ntt_tables[log_n] = std::move(t);
     return raw;
 }
 
-// In-place from the caller's view: the result ends in `data`; `tmp` (N elements) is scratch.
-void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset) {
+// Out of place: the transform of `src` ends in `dst` (N elements each); `src` is scratch afterwards (the column passes
+// run in place on it, the last pass writes `dst`) — callers ping-pong two buffers instead of copying a result back
+// (round 1 ended every transform with a device-to-device copy: 7 x 64 N bytes per proof).
+// pw (optional): the witness map's point-wise stage fused into the first pass's load: src[i] <- (src[i]*b[i] - c[i]) / Z.
+Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool coset, const NttPointwise *pw) {
     bool &lds_attr_set = ctx->lds_attr_ntt;          // per ctx (= per device)
     if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles, or a 144 KiB tile: above the 64 KiB default dynamic-LDS cap
         for (const void *f : {reinterpret_cast<const void *>(ntt_pass_cols), reinterpret_cast<const void *>(ntt_pass_rows),
@@ -426,15 +446,27 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
     const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
     const int post_const_on = (inverse && !coset) ? 1 : 0;
     a.post_const = t->n_inv;
+    if (pw) {
+        if (pre) throw HipError{hipErrorInvalidValue, "ntt: point-wise fusion needs a transform without a coset pre-multiply", __FILE__, __LINE__};
+        a.pw_zinv = pw->zinv;
+        a.pw_zc = fru_repack(fp_mul(pw->zinv, fr_from_u64_host((uint64_t)1 << 15)));      // zinv * 2^15 * 2^256 = zinv 2^271 as an integer
+    }
+    // the pass that touches the input first carries the coset pre-multiply / the fused point-wise stage
+    auto first = [&](NttPassArgs &p) {
+        p.pre = pre;
+        if (pw) { p.pw_b = pw->b; p.pw_c = pw->c; }
+    };
     auto lds_bytes = [uform](int log_m) { return (size_t)(uform ? 9 : 8) * 4 * (NTT_TILE + (log_m > 0 ? (1 << (log_m - 1)) : 1)); };
 
     if (uform && ctx->opt_ntt_mode != 3 && log_n > 2 * NTT_MAX_SUB_LOG && log_n <= 24) {
         // 2^23, 2^24: two passes over 4096-point tiles (N1 = 2^(log_n - 12) columns-first, N2 = 2^12) with the sub-transform
         // twiddles read from a U-form table in global memory, instead of three passes over 2048-point tiles
         if (!t->wu.p) {
-            t->wu.alloc(n * 9 * sizeof(uint32_t));
-            hipLaunchKernelGGL(ntt_wu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->w.as<Fr>(), t->wu.as<uint32_t>(), n);
+            DevBuf wu(n * 9 * sizeof(uint32_t));
+            hipLaunchKernelGGL(ntt_wu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->w.as<Fr>(), wu.as<uint32_t>(), n);
             ZK_HIP(hipGetLastError());
+            ZK_HIP(hipStreamSynchronize(ctx->stream));      // first use only: other streams of this ctx may read the table next
+            t->wu = std::move(wu);                          // cached only once it is complete
         }
         a.wu = t->wu.as<uint32_t>();
         a.log_n2 = 12;
@@ -443,7 +475,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         {
             NttPassArgs p1 = a;
             p1.in = data; p1.out = data;
-            p1.pre = pre;
+            first(p1);
             p1.batch_stride = 0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (12 - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
@@ -463,7 +495,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         a.log_n2 = log_n;
         a.in = data;
         a.out = tmp;
-        a.pre = pre;
+        first(a);
         a.post = post;
         a.post_const_on = post_const_on;
         ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
@@ -474,7 +506,8 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         const int log_n0 = log_n - log_m;
         if (log_n0 > 0) {
             NttPassArgs p0 = a;
-            p0.in = data; p0.out = data; p0.pre = pre;
+            p0.in = data; p0.out = data;
+            first(p0);
             p0.log_n1 = log_n0; p0.log_n2 = log_m;
             const unsigned grid = (unsigned)(((size_t)1 << log_m) >> (NTT_TILE_LOG - log_n0));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
@@ -486,7 +519,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         {
             NttPassArgs p1 = a;
             p1.in = data; p1.out = data;
-            p1.pre = log_n0 > 0 ? nullptr : pre;
+            if (log_n0 == 0) first(p1);
             p1.tw_shift = log_n0;
             p1.batch_stride = (size_t)1 << log_m;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (NTT_TILE_LOG - a.log_n1));
@@ -506,7 +539,7 @@ void ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool co
         }
     }
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(data, tmp, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    return tmp;
 }
 
 }  // namespace zk

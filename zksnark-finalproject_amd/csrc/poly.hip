@@ -98,22 +98,28 @@ void fr_from_mont_run(zkg16_ctx *ctx, const Fr *in, Fr *out, size_t n) {
 }
 
 // h = coset_ifft( (coset_fft(ifft a) * coset_fft(ifft b) - coset_fft(ifft c)) / Z ), N Montgomery coefficients.
-// Result pointer = ctx->poly[0].
+// The transforms ping-pong between each vector and the one scratch buffer (ifft: x -> tmp, coset fft: tmp -> x), and the
+// point-wise (ab - c)/Z rides on the load of the seventh transform: no device-to-device copy and no separate point-wise
+// pass (round 1 had both: 8 extra passes over N x 32 B per proof).  Result pointer = ctx->poly[3].
 void witness_map_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr **h_out) {
     const size_t n = (size_t)1 << m.log_n;
     for (int i = 0; i < 4; i++) ctx->poly[i].ensure(n * sizeof(Fr));
     Fr *a = ctx->poly[0].as<Fr>(), *b = ctx->poly[1].as<Fr>(), *c = ctx->poly[2].as<Fr>(), *tmp = ctx->poly[3].as<Fr>();
     spmv_run(ctx, m, z, a, b, c);
     ntt_run(ctx, a, tmp, m.log_n, true, false);
+    ntt_run(ctx, tmp, a, m.log_n, false, true);
     ntt_run(ctx, b, tmp, m.log_n, true, false);
-    ntt_run(ctx, a, tmp, m.log_n, false, true);
-    ntt_run(ctx, b, tmp, m.log_n, false, true);
+    ntt_run(ctx, tmp, b, m.log_n, false, true);
     ntt_run(ctx, c, tmp, m.log_n, true, false);
-    ntt_run(ctx, c, tmp, m.log_n, false, true);
+    ntt_run(ctx, tmp, c, m.log_n, false, true);
     NttTables *t = ntt_get_tables(ctx, m.log_n);
-    pointwise_h_run(ctx, a, b, c, t->zinv, n);
-    ntt_run(ctx, a, tmp, m.log_n, true, true);
-    *h_out = a;
+    if (ctx->opt_fuse_pointwise) {
+        const NttPointwise pw{b, c, t->zinv};
+        *h_out = ntt_run(ctx, a, tmp, m.log_n, true, true, &pw);
+    } else {
+        pointwise_h_run(ctx, a, b, c, t->zinv, n);
+        *h_out = ntt_run(ctx, a, tmp, m.log_n, true, true);
+    }
 }
 
 }  // namespace zk

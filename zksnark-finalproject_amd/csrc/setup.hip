@@ -117,9 +117,9 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
     const Fr dinv = fp_inv(delta), ginv = fp_inv(gamma);
 
     // L = ifft((tau^j)_j)
-    DevBuf L(N * sizeof(Fr)), tmp(N * sizeof(Fr));
-    fr_powers_run(ctx, L.as<Fr>(), tau, Fr::one(), N);
-    ntt_run(ctx, L.as<Fr>(), tmp.as<Fr>(), m.log_n, true, false);
+    DevBuf Lsrc(N * sizeof(Fr)), L(N * sizeof(Fr));
+    fr_powers_run(ctx, Lsrc.as<Fr>(), tau, Fr::one(), N);
+    ntt_run(ctx, Lsrc.as<Fr>(), L.as<Fr>(), m.log_n, true, false);      // out of place: the transform ends in L
 
     // u, v, w: per-matrix column sums
     DevBuf uvw[3];
@@ -159,7 +159,7 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
     if (res) {      // resident key (whole key on this device): layouts as in zkg16_pk_load with shard 0 of 1
         res->num_instance = ni; res->m_total = nv; res->n_h_total = N - 1;
         res->z_lo = 0; res->z_hi = nv; res->h_lo = 0; res->h_hi = N - 1;
-        res->shard_index = 0; res->shard_count = 1;
+        res->blinding = true; res->full = true;
         res->a.alloc((nv + 3) * sizeof(G1AffineU)); res->b1.alloc((nv + 3) * sizeof(G1AffineU)); res->l.alloc((nv + 3) * sizeof(G1AffineU));
         res->b2.alloc((nv + 3) * sizeof(G2AffineU)); res->h.alloc((N > 1 ? N - 1 : 1) * sizeof(G1AffineU));
         ZK_HIP(hipMemsetAsync(res->a.p, 0, res->a.bytes, ctx->stream));

@@ -58,6 +58,25 @@ class Device:
             num_instance, shard_index, shard_count, C.byref(handle)))
         return handle.value
 
+    def pk_load_range(self, pk, num_instance, z_lo, z_hi, h_lo, h_hi, blinding):
+        """A shard given by explicit index ranges (zkg16_pk_load_range); see shard_plan."""
+        a, b1, b2 = _u64(pk["a_query"]).reshape(-1, 12), _u64(pk["b_g1_query"]).reshape(-1, 12), _u64(pk["b_g2_query"]).reshape(-1, 24)
+        h, l = _u64(pk["h_query"]).reshape(-1, 12), _u64(pk["l_query"]).reshape(-1, 12)
+        infs = [_opt_u8(pk.get(k)) for k in ("a_inf", "b_g1_inf", "b_g2_inf", "h_inf", "l_inf")]
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_pk_load_range(
+            self.ctx, a, _ptr(infs[0]), a.shape[0], b1, _ptr(infs[1]), b1.shape[0], b2, _ptr(infs[2]), b2.shape[0],
+            _ptr(h), _ptr(infs[3]), h.shape[0], _ptr(l), _ptr(infs[4]), l.shape[0],
+            _u64(pk["alpha_g1"]), _u64(pk["beta_g1"]), _u64(pk["beta_g2"]), _u64(pk["delta_g1"]), _u64(pk["delta_g2"]),
+            num_instance, z_lo, z_hi, h_lo, h_hi, int(bool(blinding)), C.byref(handle)))
+        return handle.value
+
+    def pk_slice(self, pk_h, z_lo, z_hi, h_lo, h_hi, blinding):
+        """A shard cut out of a whole resident key, device to device (zkg16_pk_slice)."""
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_pk_slice(self.ctx, pk_h, z_lo, z_hi, h_lo, h_hi, int(bool(blinding)), C.byref(handle)))
+        return handle.value
+
     def pk_free(self, h):
         self.lib.zkg16_pk_free(self.ctx, h)
 
@@ -160,6 +179,12 @@ class Device:
         self._check(self.lib.zkg16_bench_ntt(self.ctx, log_n, int(inverse), int(coset), iters, C.byref(ms)))
         return ms.value
 
+    def bench_witness_map(self, r1cs_h, wit_h, iters=3):
+        """ms per stand-alone witness map (3 SpMV + 7 NTT + point-wise) on resident inputs."""
+        ms = C.c_float()
+        self._check(self.lib.zkg16_bench_witness_map(self.ctx, r1cs_h, wit_h, iters, C.byref(ms)))
+        return ms.value
+
     def witness_map(self, r1cs_h, wit_h, n_max):
         h = np.zeros((n_max, 4), dtype=np.uint64)
         log_n = C.c_size_t()
@@ -197,6 +222,20 @@ class Device:
 
     def set_option(self, name, value):
         self._check(self.lib.zkg16_set_option(self.ctx, name.encode(), int(value)))
+
+
+def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0):
+    """Rank roles of one proof over n_ranks GPUs (host-only zkg16_shard_plan) ->
+    (list of (z_lo, z_hi, h_lo, h_hi, blinding) per rank, number of ranks that run the witness map)."""
+    lib = _lib.load()
+    ranges = np.zeros(4 * n_ranks, dtype=np.uint64)
+    blind = np.zeros(n_ranks, dtype=np.uint8)
+    k = C.c_int(0)
+    rc = lib.zkg16_shard_plan(n_ranks, m_total, n_h, float(b_density), h_ranks, ranges, blind, C.byref(k))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    r = ranges.reshape(n_ranks, 4)
+    return [(int(r[i, 0]), int(r[i, 1]), int(r[i, 2]), int(r[i, 3]), bool(blind[i])) for i in range(n_ranks)], k.value
 
 
 def combine_partials(alpha_g1, beta_g1, beta_g2, r, s, partials, partial_inf):
