@@ -439,7 +439,7 @@ def main():
             nz, nh = zz.shape[0], shp["domain"] - 1
 
             def nwin(n):
-                return 254 // (16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
+                return 254 // (17 if n >= (1 << 23) else 16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
             z_entries = (nz - n_one - n_zero) * nwin(nz) + n_one
             h_entries = nh * nwin(nh)
             gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -57,6 +57,11 @@ template <class FS, class FU> static void fieldu_op(int op, const uint32_t *a, c
         case 5: r = f_neg(x); break;
         case 6: r = f_sub2(x, y); break;
         case 8: r = f_tidy(f_mul(f_inv(f_mul(x, y)), y)); break;      // inverse of an un-reduced product, tidied: == 1/x
+        case 9: {   // the fused Y3 of the mixed addition: a*b - c*d with c a stored coordinate at its documented bound (< 42q)
+            FU cbig = f_sub(f_mul(x, x), f_add(f_mul(x, y), f_dbl(f_mul(y, y))));    // == x^2 - xy - 2y^2, value < 2q + 32q + ...
+            r = f_mul_sub(f_sub2(x, y), f_add(x, y), cbig, f_sub2(y, x));
+            break;
+        }
         case 7: {   // bound stress: a long un-reduced expression inside the documented limits
             FU t = f_sub2(f_mul(x, y), f_sub(f_add(x, y), f_dbl(y)));      // < 2q + 64q
             FU u = f_sub(f_sqr(t), f_add(f_mul(t, x), f_dbl(f_mul(t, y)))); // < 42q
@@ -105,6 +110,14 @@ extern "C" void ht_fru_op(int op, const uint32_t *a, const uint32_t *b, uint32_t
         case 3: r = fru_mul(fru_sub_2r(x, y), y); break;                    // (a - b) b with the un-reduced difference (< 4r)
         case 4: st(o, fru_mul_to_sat(x, fru_repack(sb))); return;           // store path: U-form times a saturated-form factor
         case 5: r = fru_mul(fru_repack(sa), fru_mul(fru_repack(sb), fru_c271())); break;     // coset load path: x g
+        case 6: {   // fused point-wise load path of the witness map's seventh transform: (a*b - b) * zc' with zc = a * 2^271 (zinv := a)
+            const Fr two15 = fp_to_mont([] { Fr c = Fr::zero(); c.l[0] = 1u << 15; return c; }());
+            const FrU zc = fru_repack(fp_mul(sa, two15));
+            const FrU xb = fru_mul(fru_repack(sa), fru_repack(sb));
+            const FrU c = fru_mul(fru_repack(sb), fru_one_sat());
+            r = fru_mul(fru_sub_2r(xb, c), zc);
+            break;
+        }
         default: r = x;
     }
     st(o, fru_mul_to_sat(r, fru_one_sat()));

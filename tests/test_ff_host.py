@@ -132,6 +132,9 @@ def test_fqu_field_ops_vs_python(shim):
         u = (t * t - (t * a + 2 * t * b)) % q
         exp = (t * (a - u) - u * b) % q
         assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 7, fq_mont(a), fq_mont(b)))) == exp
+        # fused product-difference with one reduction (fqu_mul2 / f_mul_sub: Y3 of the mixed addition)
+        exp9 = ((a - b) * (a + b) - (a * a - a * b - 2 * b * b) * (b - a)) % q
+        assert P.fq_from_mont(unlimbs(call_field(shim, "ht_fqu_op", 9, fq_mont(a), fq_mont(b)))) == exp9
 
 
 def test_fqu_inverse_vs_python(shim):
@@ -217,7 +220,7 @@ def test_fru_ops_vs_python(shim):
     r = P.R_MOD
     vals = [0, 1, 2, r - 1, r - 2, (1 << 254) % r, (1 << 255) % r] + [rng.randrange(r) for _ in range(60)]
     ops = ((0, lambda x, y: x + y), (1, lambda x, y: x - y), (2, lambda x, y: x * y), (3, lambda x, y: (x - y) * y),
-           (4, lambda x, y: x * y), (5, lambda x, y: x * y))
+           (4, lambda x, y: x * y), (5, lambda x, y: x * y), (6, lambda x, y: (x * y - y) * x))
     for a in vals[:9]:
         for b in vals[:9]:
             for op, f in ops:

@@ -1,33 +1,37 @@
-"""A/B a library option in one process (development probe): python tools/ab_option.py <option> <v0,v1,...> [matrix_n]"""
+"""A/B library options in one process (development probe, GPU box):
+   python tools/ab_option.py <matrix_n> <opt=v0,v1,...> [<opt2=...> ...]     (options are swept one at a time, the others at 0/default)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import bench
 from zksnark_finalproject_amd import Device
-from zksnark_finalproject_amd.circuits import matrix_circuit
-opt = sys.argv[1]
-vals = [int(x) for x in sys.argv[2].split(",")]
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+from zksnark_finalproject_amd.device import verify
+n = int(sys.argv[1])
+sweeps = [(a.split("=")[0], [int(x) for x in a.split("=")[1].split(",")]) for a in sys.argv[2:]]
 dev = Device(0)
-c = matrix_circuit(np.ones((n, n), dtype=np.uint64), np.ones((n, n), dtype=np.uint64))
-shp = dict(num_vars=c.num_vars, num_instance=c.num_instance, domain=c.domain)
-pk = bench.make_key(dev, c.r1cs, shp, seed=1)
-ph, rh, wh = dev.pk_load(pk, 4), dev.r1cs_load(c.r1cs, c.num_vars), dev.witness_load(c.z)
-rng = np.random.default_rng(5)
-r, s = bench.rand_fr_mont(rng), bench.rand_fr_mont(rng)
+trap, g1, g2 = bench.draw_key_inputs(7)
+c, _, desc = bench.synthesize("matrix", n)
+rh = dev.r1cs_load(c.r1cs, c.num_vars)
+ph, vk = dev.setup_resident(rh, c.num_instance, trap, g1, g2)
+wh = dev.witness_load(c.z)
+r, s = bench.fr_mont(12345), bench.fr_mont(67890)
 ref = dev.prove_resident(ph, rh, wh, r, s)
-res = {v: [] for v in vals}
-same = True
-for rnd in range(6):
+print(desc, "verified:", verify(vk, c.public_inputs, *ref), flush=True)
+reps = 3 if n >= 100 else 5
+for opt, vals in sweeps:
+    res = {v: [] for v in vals}
+    same = True
+    for rnd in range(3 if n >= 100 else 6):
+        for v in vals:
+            dev.set_option(opt, v)
+            out = dev.prove_resident(ph, rh, wh, r, s)
+            same = same and np.array_equal(out[0], ref[0])
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dev.prove_resident(ph, rh, wh, r, s)
+            res[v].append((time.perf_counter() - t0) / reps * 1e3)
+    dev.set_option(opt, 0 if opt != "wm_concurrent" else -1)
     for v in vals:
-        dev.set_option(opt, v)
-        out = dev.prove_resident(ph, rh, wh, r, s)
-        same = same and np.array_equal(out[0], ref[0])
-        t0 = time.perf_counter()
-        for _ in range(5):
-            dev.prove_resident(ph, rh, wh, r, s)
-        res[v].append((time.perf_counter() - t0) / 5 * 1e3)
-for v in vals:
-    x = sorted(res[v])
-    print("n=%d %s=%d  ms/proof min %.2f median %.2f max %.2f  (proofs identical: %s)" % (n, opt, v, x[0], x[len(x) // 2], x[-1], same))
+        x = sorted(res[v])
+        print("n=%d %s=%d  ms/proof min %.2f median %.2f max %.2f  (proofs identical: %s)" % (n, opt, v, x[0], x[len(x) // 2], x[-1], same), flush=True)

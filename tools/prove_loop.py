@@ -1,20 +1,20 @@
-"""A bare loop of resident proofs (profiling target): python tools/prove_loop.py [matrix_n] [proofs]"""
+"""A bare loop of resident proofs (profiling target): python tools/prove_loop.py [matrix_n] [proofs] [opt=value ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import bench
 from zksnark_finalproject_amd import Device
-from zksnark_finalproject_amd.circuits import matrix_circuit
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-circ = matrix_circuit(np.ones((n, n), dtype=np.uint64), np.ones((n, n), dtype=np.uint64))
-shp = dict(n=n, nc=circ.num_constraints, num_instance=circ.num_instance, num_witness=circ.num_witness, num_vars=circ.num_vars, domain=circ.domain)
 dev = Device(0)
-pk = bench.make_key(dev, circ.r1cs, shp, seed=0xC0FFEE)
-ph, rh, wh = dev.pk_load(pk, shp["num_instance"]), dev.r1cs_load(circ.r1cs, shp["num_vars"]), dev.witness_load(circ.z)
-rng = np.random.default_rng(5)
-r, s = bench.rand_fr_mont(rng), bench.rand_fr_mont(rng)
+for a in sys.argv[3:]:
+    dev.set_option(a.split("=")[0], int(a.split("=")[1]))
+trap, g1, g2 = bench.draw_key_inputs(7)
+c, _, desc = bench.synthesize("matrix", n)
+rh = dev.r1cs_load(c.r1cs, c.num_vars)
+ph, vk = dev.setup_resident(rh, c.num_instance, trap, g1, g2)
+wh = dev.witness_load(c.z)
+r, s = bench.fr_mont(12345), bench.fr_mont(67890)
 for _ in range(k):
     dev.prove_resident(ph, rh, wh, r, s)
-print("done", dev.last_timings())
+print("done", desc, dev.last_timings())

@@ -8,8 +8,11 @@ def short(n):
     n = re.sub(r'\(.*', '', n).replace('zk::', '').replace('void ', '')
     n = re.sub(r'rocprim::.*trampoline_kernel<rocprim::ROCPRIM_400200_NS::detail::', 'rp::', n)
     return n[:48]
-idx = [i for i, r in enumerate(rows) if 'fr_from_mont' in r[0]]
-sub = rows[idx[-2]:]
+# a proof starts with the z-side digit kernel: the last proof = from the third-last digit launch on small/medium circuits
+# (z, z masked by the B density, h); pass the number of digit launches per proof as argv[3] when it differs
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+idx = [i for i, r in enumerate(rows) if 'msm_digits' in r[0]]
+sub = rows[idx[-per]:]
 t0 = sub[0][1]
 for r in sub:
     if (r[2] - r[1]) / 1e6 >= min_ms:

@@ -320,6 +320,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // ---- H last: it is the only MSM that waits for the witness map; then collect — each MSM's host Horner overlaps the
     // device work still queued behind it
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
+    ctx->slots[1].last_of_proof = true;
     if (nh) msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
     if (trace) fprintf(stderr, "host: h queued at %.3f ms\n", now_ms() - t0);
     double tprev = now_ms();
@@ -571,7 +572,7 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return ZKG16_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!strcmp(name, "window_bits")) {
-        if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
+        if (value != 0 && (value < 2 || value > 20)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits = (int)value;
         return ZKG16_OK;
     }
@@ -586,8 +587,8 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "reduce_mode")) {
-        if (value < 0 || value > 1) return ZKG16_ERR_BAD_ARG;
-        ctx->opt_reduce_mode = (int)value;
+        if (value < 0 || value > 4) return ZKG16_ERR_BAD_ARG;      // 4 = classic everywhere (0 restores the default, 3)
+        ctx->opt_reduce_mode = value == 0 ? 3 : (value == 4 ? 0 : (int)value);
         return ZKG16_OK;
     }
     if (!strcmp(name, "g1_waves")) {
@@ -600,12 +601,22 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "window_bits_h")) {
-        if (value != 0 && (value < 2 || value > 16)) return ZKG16_ERR_BAD_ARG;
+        if (value != 0 && (value < 2 || value > 20)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits_h = (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "wm_concurrent")) {      // -1 auto (default), 0 in-order, 1 third stream
         ctx->opt_wm_concurrent = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "sort_mode")) {          // 0 (default): hand-written wave-ballot bucket scatter; 1: rocPRIM device radix sort
+        if (value < 0 || value > 1) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_sort_mode = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "acc_pipeline")) {       // bit 0: G1, bit 1: G2 (default 3); 4 = both off (0 restores the default)
+        if (value < 0 || value > 4) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_acc_pipeline = value == 0 ? 3 : (value == 4 ? 0 : (int)value);
         return ZKG16_OK;
     }
     if (!strcmp(name, "fuse_pointwise")) {     // 1 (default): (ab - c)/Z on the load of the seventh transform; 0: own pass
@@ -746,6 +757,7 @@ int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t src_handle, size_t z_lo, size_t z_hi
 //   T(k) = max( (Z + H + k * WM) / n_ranks,  WM + H / k ),
 // and k is the one that minimises T (k = n_ranks is the homogeneous split of round 1: every rank repeats the witness map).
 static int default_window_bits(size_t n) {
+    if (n >= ((size_t)1 << 23)) return 17;
     if (n >= ((size_t)1 << 20)) return 16;
     if (n >= ((size_t)1 << 17)) return 15;
     if (n >= ((size_t)1 << 14)) return 13;

@@ -118,6 +118,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
     int nwin = 0, c = 0;
     bool active = false;
     bool pending_reduce = false;    // accumulation queued, reduction not yet (msm_*_enqueue_reduce)
+    bool last_of_proof = false;     // this MSM's reduction is the tail of the proof (nothing left to overlap it)
     bool fixups_pending = false;    // fix-ups go with the reduction (aux stream) instead of the accumulation (main stream)
     alignas(16) unsigned char acc_args[128] = {0};
     unsigned acc_grid = 0;
@@ -127,7 +128,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 };
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
-    DevBuf keys, entries, offsets, seg_params, scalars, stage, sort_temp;
+    DevBuf keys, entries, offsets, seg_params, scalars, stage, sort_temp, codes;
 };
 
 }  // namespace zk
@@ -155,12 +156,14 @@ struct zkg16_ctx {
     int opt_window_bits = 0;
     int opt_min_seg = 0;                              // shortest per-lane run of sorted entries in an accumulation (0 = default)
     int opt_ntt_mode = 1;                             // 1: unsaturated (29-bit limb) butterflies, 0: saturated
-    int opt_reduce_mode = 0;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level
+    int opt_reduce_mode = 3;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level, 2 = 1 except the proof's last MSM, 3 (default) = 2 from 16-bit windows on
     int opt_g1_waves = 0;                             // G1 accumulation waves per SIMD in the one resident round (0 = 2)
     int opt_fixup_aux = 0;                            // 1: fix-up kernels on the MSM's reduction stream
     int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
+    int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
+    int opt_acc_pipeline = 3;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product
     int opt_fuse_pointwise = 1;                       // (ab - c)/Z on the load of the seventh transform (0: its own pass)
     int num_cus = 256;
     bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
@@ -209,7 +212,9 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 // (converted inside the digit kernel); mask[i] != 0 zeroes scalar i (B-query density filter).  All device pointers.
 struct ScalarSrc { const Fr *main; size_t n_main; const Fr *extra; size_t n_extra; bool mont; const uint8_t *mask; };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits = 0);
-void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort)
+void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort; option sort_mode 1)
+// bucket_sort.hip: hand-written wave-ballot counting scatter (default); returns the per-window entry counts (device)
+const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t *codes, size_t n, int nwin, int c, uint2 *entries);
 void radix_sort_hi32(zkg16_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, unsigned key_bits, DevBuf &temp, const char *timer_name);
 // setup.hip: Groth16 key generation from a known trapdoor (discrete logs on device, then fixed-base batches)
 struct SetupOut {

@@ -90,7 +90,7 @@ ZK_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bool neg) {
     F PPP = f_mul(Pp, PP);
     F Q = f_mul(acc.x, PP);
     F X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
-    acc.y = f_sub(f_mul(R, f_sub2(Q, X3)), f_mul(acc.y, PPP));
+    acc.y = f_mul_sub(R, f_sub2(Q, X3), acc.y, PPP);      // R (Q - X3) - Y1 PPP: one reduction in the unsaturated G1 form
     acc.x = X3;
     acc.zz = f_mul(acc.zz, PP);
     acc.zzz = f_mul(acc.zzz, PPP);
@@ -123,6 +123,89 @@ ZK_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
     acc.x = X3;
     acc.zz = f_mul(f_mul(acc.zz, q.zz), PP);
     acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), PPP);
+}
+
+// ---- the mixed addition in two parts for the bucket-accumulation kernels (msm.hip).  Every field product is a device-function
+// call except ONE, which is inlined and done last (`finish`): a call boundary drains all outstanding memory operations
+// (s_waitcnt vmcnt(0) at every function entry), so the gather of the NEXT base can only stay in flight across call-free code.
+// The kernels issue that gather between `front` and `finish`; the ~600 inlined instructions of the last product hide it.
+//   G1 (FqU):  finish = Y3 = R (Q - X3) + (-Y1) PPP   (the fused two-product reduction)
+//   G2 (Fq2U): finish = ZZZ3 = ZZZ1 * PPP            (one Fq2 product, three inlined Fq products)
+// front() does everything else, including all exceptional cases (then it returns false and finish() changes nothing).
+template <class F> struct MaddTail { F a, b, c, d; };
+
+ZK_HD bool xyzz_madd_front(XYZZ<FqU> &acc, const Affine<FqU> &q_in, bool neg, MaddTail<FqU> &t) {
+    if (q_in.is_inf()) { t.a = t.b = t.c = t.d = FqU::zero(); return false; }
+    Affine<FqU> q = q_in;
+    if (neg) q.y = f_neg(q.y);
+    if (acc.is_inf()) {
+        acc = XYZZ<FqU>{q.x, q.y, FqU::one(), FqU::one()};
+        t.a = t.b = t.c = t.d = FqU::zero();
+        return false;
+    }
+    FqU U2 = f_mul(q.x, acc.zz);
+    FqU S2 = f_mul(q.y, acc.zzz);
+    FqU Pp = f_sub2(U2, acc.x);
+    FqU R = f_sub2(S2, acc.y);
+    if (f_is_zero_mod(Pp)) {
+        if (f_is_zero_mod(R)) acc = xyzz_dbl_affine(q);
+        else acc = XYZZ<FqU>::inf();
+        t.a = t.b = t.c = t.d = FqU::zero();
+        return false;
+    }
+    // order chosen for register pressure: at most six field elements are live across any call (values that survive a call
+    // must sit in the callee-saved half of the register file)
+    FqU PP = f_sqr(Pp);
+    FqU PPP = f_mul(Pp, PP);
+    acc.zz = f_mul(acc.zz, PP);
+    acc.zzz = f_mul(acc.zzz, PPP);
+    FqU Q = f_mul(acc.x, PP);
+    FqU X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    t.a = R;
+    t.b = f_sub2(Q, X3);
+    t.c = fqu_sub<64>(FqU::zero(), acc.y);
+    t.d = PPP;
+    acc.x = X3;
+    return true;
+}
+ZK_HD void xyzz_madd_finish(XYZZ<FqU> &acc, const MaddTail<FqU> &t, bool normal) {
+    const FqU y = fqu_mul2(t.a, t.b, t.c, t.d);
+    if (normal) acc.y = y;
+}
+
+ZK_HD bool xyzz_madd_front(XYZZ<Fq2U> &acc, const Affine<Fq2U> &q_in, bool neg, MaddTail<Fq2U> &t) {
+    if (q_in.is_inf()) { t.a = t.b = Fq2U::zero(); return false; }
+    Affine<Fq2U> q = q_in;
+    if (neg) q.y = f_neg(q.y);
+    if (acc.is_inf()) {
+        acc = XYZZ<Fq2U>{q.x, q.y, Fq2U::one(), Fq2U::one()};
+        t.a = t.b = Fq2U::zero();
+        return false;
+    }
+    Fq2U U2 = f_mul(q.x, acc.zz);
+    Fq2U S2 = f_mul(q.y, acc.zzz);
+    Fq2U Pp = f_sub2(U2, acc.x);
+    Fq2U R = f_sub2(S2, acc.y);
+    if (f_is_zero_mod(Pp)) {
+        if (f_is_zero_mod(R)) acc = xyzz_dbl_affine(q);
+        else acc = XYZZ<Fq2U>::inf();
+        t.a = t.b = Fq2U::zero();
+        return false;
+    }
+    Fq2U PP = f_sqr(Pp);
+    Fq2U PPP = f_mul(Pp, PP);
+    acc.zz = f_mul(acc.zz, PP);
+    Fq2U Q = f_mul(acc.x, PP);
+    Fq2U X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    acc.y = f_sub(f_mul(R, f_sub2(Q, X3)), f_mul(acc.y, PPP));
+    acc.x = X3;
+    t.a = acc.zzz;
+    t.b = PPP;
+    return true;
+}
+ZK_HD void xyzz_madd_finish(XYZZ<Fq2U> &acc, const MaddTail<Fq2U> &t, bool normal) {
+    const Fq2U z = fq2u_mul_inline(t.a, t.b);
+    if (normal) acc.zzz = z;
 }
 
 template <class F>

@@ -183,6 +183,40 @@ ZK_HD FqU fqu_mul_impl(const FqU &a, const FqU &b) {
     return r;
 }
 
+// a*b + c*d with ONE Montgomery reduction: (ab + cd) 2^-406 mod q.  A column holds <= 28 partial products and <= 14 reduction
+// products, each < 2^58: < 2^63.4, still one 64-bit accumulator.  Inputs normalised, < 2^12 q; output normalised, < 2q
+// ((2 * 2^24 q^2 + 2^406 q) / 2^406 < 2q).  Always inlined (four operands = 56 registers do not fit the 32 argument VGPRs of
+// a device-function call): used once per mixed addition, for Y3 = R (Q - X3) + (-Y1) PPP.
+ZK_HD FqU fqu_mul2(const FqU &a, const FqU &b, const FqU &c, const FqU &d) {
+    constexpr int N = 14;
+    uint32_t m[N];
+    FqU r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+        const int lo = k < N ? 0 : k - N + 1;
+        const int hi = k < N ? k : N - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = lo; i <= hi; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+        if (k < N) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FqUP::mod(k - i);
+            m[k] = ((uint32_t)acc * FqUP::INV) & FqU::MASK;
+            acc += (uint64_t)m[k] * FqUP::mod(0);
+            acc >>= 29;
+        } else {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) acc += (uint64_t)m[i] * FqUP::mod(k - i);
+            r.l[k - N] = (uint32_t)acc & FqU::MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[N - 1] = (uint32_t)acc;
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // one copy of each body per code object (see the note on fq_mul_call in ff.cuh); 28 VGPR arguments
 typedef uint32_t zk_v2u __attribute__((ext_vector_type(2)));
@@ -315,6 +349,8 @@ ZK_HD FqU f_dbl(const FqU &a) { return fqu_dbl(a); }
 ZK_HD FqU f_mul(const FqU &a, const FqU &b) { return fqu_mul(a, b); }
 ZK_HD FqU f_sqr(const FqU &a) { return fqu_sqr(a); }
 ZK_HD bool f_is_zero_mod(const FqU &a) { return fqu_is_zero_mod(a); }
+// a*b - c*d for a stored coordinate c (<= 63 q): one reduction instead of two (fqu_mul2); result < 2q
+ZK_HD FqU f_mul_sub(const FqU &a, const FqU &b, const FqU &c, const FqU &d) { return fqu_mul2(a, b, fqu_sub<64>(FqU::zero(), c), d); }
 
 // ------------------------------------------------------------------------------------------------ Fq2 over U-form
 struct Fq2U {
@@ -335,6 +371,14 @@ ZK_HD Fq2U f_mul(const Fq2U &a, const Fq2U &b) {
     const FqU s = fqu_mul(fqu_add(a.c0, a.c1), fqu_add(b.c0, b.c1));
     return Fq2U{fqu_sub<8>(v0, v1), fqu_sub<8>(s, fqu_add(v0, v1))};
 }
+// the same product with the three Fq products inlined (no call boundary): the last product of a G2 mixed addition, behind
+// which the accumulation kernel hides the gather of the next base (ec.cuh: xyzz_madd_finish)
+ZK_HD Fq2U fq2u_mul_inline(const Fq2U &a, const Fq2U &b) {
+    const FqU v0 = fqu_mul_impl<false>(a.c0, b.c0);
+    const FqU v1 = fqu_mul_impl<false>(a.c1, b.c1);
+    const FqU s = fqu_mul_impl<false>(fqu_add(a.c0, a.c1), fqu_add(b.c0, b.c1));
+    return Fq2U{fqu_sub<8>(v0, v1), fqu_sub<8>(s, fqu_add(v0, v1))};
+}
 ZK_HD Fq2U f_sqr(const Fq2U &a) {
     // (c0+c1)(c0-c1) + 2 c0 c1 u ; squared values are differences of stored coordinates (components < 74q, or 84q for
     // 2*Y in a doubling) -> level-128 subtraction
@@ -343,6 +387,7 @@ ZK_HD Fq2U f_sqr(const Fq2U &a) {
     return Fq2U{r0, fqu_dbl(p)};
 }
 ZK_HD bool f_is_zero_mod(const Fq2U &a) { return fqu_is_zero_mod(a.c0) && fqu_is_zero_mod(a.c1); }
+ZK_HD Fq2U f_mul_sub(const Fq2U &a, const Fq2U &b, const Fq2U &c, const Fq2U &d) { return f_sub(f_mul(a, b), f_mul(c, d)); }
 
 ZK_HD Fq2U fq2u_from_sat(const Fq2 &s) { return Fq2U{fqu_from_sat(s.c0), fqu_from_sat(s.c1)}; }
 ZK_HD Fq2 fq2u_to_sat(const Fq2U &u) { return Fq2{fqu_to_sat(u.c0), fqu_to_sat(u.c1)}; }
@@ -381,6 +426,8 @@ ZK_HD Fq2U f_tidy(const Fq2U &a) { return Fq2U{fqu_mul(a.c0, FqU::one()), fqu_mu
 // saturated types: second-level subtraction and the mod test are the plain ones
 ZK_HD Fq f_sub2(const Fq &a, const Fq &b) { return fp_sub(a, b); }
 ZK_HD Fq2 f_sub2(const Fq2 &a, const Fq2 &b) { return f_sub(a, b); }
+ZK_HD Fq f_mul_sub(const Fq &a, const Fq &b, const Fq &c, const Fq &d) { return f_sub(f_mul(a, b), f_mul(c, d)); }
+ZK_HD Fq2 f_mul_sub(const Fq2 &a, const Fq2 &b, const Fq2 &c, const Fq2 &d) { return f_sub(f_mul(a, b), f_mul(c, d)); }
 ZK_HD bool f_is_zero_mod(const Fq &a) { return a.is_zero(); }
 ZK_HD bool f_is_zero_mod(const Fq2 &a) { return a.is_zero(); }
 

@@ -61,7 +61,7 @@ struct DigitSrc {
     const uint8_t *mask;
     int mont;
 };
-__global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, int nwin, size_t nb, uint64_t *keys, uint32_t invalid_bucket) {
+__global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, int nwin, size_t nb, uint64_t *keys, uint32_t *codes, uint32_t invalid_bucket) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = src.n;
     if (i >= n) return;
@@ -115,16 +115,26 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, in
         } else if (v != 0) {
             key = 1u + (((v - 1u) << 1) | flipbit);
         }
-        const uint32_t g = key ? (uint32_t)((size_t)w * nb + ((key - 1u) >> 1)) : invalid_bucket;
-        keys[(size_t)w * n + i] = ((uint64_t)g << 32) | (uint64_t)(((uint32_t)i << 1) | ((key - 1u) & 1u));
+        if (codes) {      // hand-written bucket scatter (bucket_sort.hip): (|d| - 1) << 1 | negate per (window, scalar), ~0 for digit 0
+            codes[(size_t)w * n + i] = key - 1u;
+        } else {          // rocPRIM path (sort.hip): 64-bit keys
+            const uint32_t g = key ? (uint32_t)((size_t)w * nb + ((key - 1u) >> 1)) : invalid_bucket;
+            keys[(size_t)w * n + i] = ((uint64_t)g << 32) | (uint64_t)(((uint32_t)i << 1) | ((key - 1u) & 1u));
+        }
     }
 }
 
 // offsets[g] = first position of the sorted entry list whose bucket id is >= g  (g = 0 .. total_buckets; the last one is the
 // number of valid entries: digit-0 keys carry bucket id = total_buckets and sort behind everything)
-__global__ void __launch_bounds__(256) msm_offsets_kernel(const uint2 *sorted, size_t count, uint32_t *offsets, size_t total_buckets) {
+// count: length of the sorted list; with the hand-written scatter it is the sum of the per-window totals on the device
+__global__ void __launch_bounds__(256) msm_offsets_kernel(const uint2 *sorted, size_t count, const uint32_t *win_total, int nwin, uint32_t *offsets,
+                                                          size_t total_buckets) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g > total_buckets) return;
+    if (win_total) {
+        count = 0;
+        for (int w = 0; w < nwin; w++) count += win_total[w];
+    }
     size_t lo = 0, hi = count;                    // answer in [lo, hi]
     while (lo < hi) {
         const size_t mid = (lo + hi) >> 1;
@@ -164,7 +174,7 @@ struct AccArgs {
 };
 
 // G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
-template <class F>
+template <class F, bool PIPE>
 __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate_kernel(AccArgs<F> a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *a.total_ptr;
@@ -179,27 +189,58 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
     int32_t head_b = -1, tail_b = -1;
     XYZZ<F> acc = XYZZ<F>::inf();
     uint32_t cur = g_first;
-    uint32_t e = en.x, gb = en.y;
-    for (uint32_t p = start; p < end; p++) {
-        // next entry's index words are fetched a full mixed addition ahead of their use
-        if (p + 1 < end) en = a.entries[p + 1];
-        const uint32_t e_n = en.x, g_n = en.y;
-        if (gb != cur) {
-            // a bucket that began in an earlier segment is this segment's HEAD partial; one that continues into the
-            // next is its TAIL partial (a bucket doing both is recorded as head only); everything else is complete.
-            if (cur == g_first && head_open) {
-                head_b = (int32_t)cur;
-                stv(a.seg_head + t, acc);
-            } else if (!acc.is_inf()) {
-                stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+    // software pipeline: entry p+1 and the base of entry p are in registers when iteration p starts.  The gather of base
+    // p+1 (and the load of entry p+2) are issued between the two parts of the mixed addition: every field product of the
+    // first part is a device-function call, and a call drains all outstanding loads, so a gather issued earlier would be
+    // waited for at once; the second part is one inlined product (~600 instructions, no call), long enough to cover it.
+    if constexpr (PIPE) {
+        uint2 en1 = start + 1 < end ? a.entries[start + 1] : en;
+        Affine<F> bq = ldv(a.bases + (en.x >> 1));
+        for (uint32_t p = start; p < end; p++) {
+            const uint32_t e = en.x, gb = en.y;
+            if (gb != cur) {
+                // a bucket that began in an earlier segment is this segment's HEAD partial; one that continues into the
+                // next is its TAIL partial (a bucket doing both is recorded as head only); everything else is complete.
+                if (cur == g_first && head_open) {
+                    head_b = (int32_t)cur;
+                    stv(a.seg_head + t, acc);
+                } else if (!acc.is_inf()) {
+                    stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+                }
+                acc = XYZZ<F>::inf();
+                cur = gb;
             }
-            acc = XYZZ<F>::inf();
-            cur = gb;
+            MaddTail<F> tail;
+            const bool normal = xyzz_madd_front(acc, bq, (e & 1u) != 0, tail);
+            // unconditional (index clamped to the segment): a load inside a branch would be followed by the copies that merge its
+            // result with the old value, and those wait for it at once.  The last iteration re-reads its own entry / base.
+            en = en1;
+            en1 = a.entries[p + 2 < end ? p + 2 : end - 1];
+            bq = ldv(a.bases + (en.x >> 1));
+            asm volatile("" ::: "memory");            // the loads above stay above the inlined product
+            xyzz_madd_finish(acc, tail, normal);
         }
-        const Affine<F> b = ldv(a.bases + (e >> 1));
-        xyzz_madd(acc, b, (e & 1u) != 0);
-        e = e_n;
-        gb = g_n;
+    } else {
+        // round-1 form: the base is gathered right before its addition (kept selectable: option "acc_pipeline")
+        uint32_t e = en.x, gb = en.y;
+        for (uint32_t p = start; p < end; p++) {
+            if (p + 1 < end) en = a.entries[p + 1];
+            const uint32_t e_n = en.x, g_n = en.y;
+            if (gb != cur) {
+                if (cur == g_first && head_open) {
+                    head_b = (int32_t)cur;
+                    stv(a.seg_head + t, acc);
+                } else if (!acc.is_inf()) {
+                    stv(a.buckets + cur, acc);
+                }
+                acc = XYZZ<F>::inf();
+                cur = gb;
+            }
+            const Affine<F> b = ldv(a.bases + (e >> 1));
+            xyzz_madd(acc, b, (e & 1u) != 0);
+            e = e_n;
+            gb = g_n;
+        }
     }
     if (cur == g_first && head_open) {
         head_b = (int32_t)cur;
@@ -555,8 +596,9 @@ batch_affine_kernel(const XYZZ<FU> *pts, size_t n, FU *pref, AffineSegs<FU> segs
 
 // ------------------------------------------------------------------------------------------------ host drivers
 static int pick_window_bits(zkg16_ctx *ctx, size_t n) {
-    if (ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 16) return ctx->opt_window_bits;
+    if (ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 20) return ctx->opt_window_bits;
     // 254-bit magnitudes: c = 16 and 15 leave a 14-bit top window, 13 a 7-bit one (c = 14 would leave 2 bits = 4 giant buckets)
+    if (n >= ((size_t)1 << 23)) return 17;         // 128x128 circuit (8.7 M / 16.8 M terms): 15 windows instead of 16; measured 191.3 -> 185.7 ms
     if (n >= ((size_t)1 << 20)) return 16;
     if (n >= ((size_t)1 << 17)) return 15;
     if (n >= ((size_t)1 << 14)) return 13;
@@ -574,30 +616,42 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits) {
     const size_t n = src.n_main + src.n_extra;
     plan.n = n;
-    plan.c = (window_bits >= 2 && window_bits <= 16) ? window_bits : pick_window_bits(ctx, n);
+    plan.c = (window_bits >= 2 && window_bits <= 20) ? window_bits : pick_window_bits(ctx, n);
     plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
     plan.nb = (size_t)1 << (plan.c - 1);
     plan.total_entries = 0;
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
     const size_t tot = n * (size_t)plan.nwin;
-    ws.keys.ensure(tot * sizeof(uint64_t));
     ws.entries.ensure(tot * sizeof(uint64_t));
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
-    {
-        ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
-        const DigitSrc d{reinterpret_cast<const uint32_t *>(src.main), reinterpret_cast<const uint32_t *>(src.extra), src.n_main, n, src.mask,
-                         src.mont ? 1 : 0};
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin, plan.nb,
-                           ws.keys.as<uint64_t>(), (uint32_t)tb);
+    const bool own_sort = ctx->opt_sort_mode == 0;
+    const DigitSrc d{reinterpret_cast<const uint32_t *>(src.main), reinterpret_cast<const uint32_t *>(src.extra), src.n_main, n, src.mask,
+                     src.mont ? 1 : 0};
+    const uint32_t *win_total = nullptr;
+    if (own_sort) {
+        ws.codes.ensure(tot * sizeof(uint32_t));
+        {
+            ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin, plan.nb,
+                               (uint64_t *)nullptr, ws.codes.as<uint32_t>(), (uint32_t)tb);
+        }
+        win_total = msm_bucket_sort(ctx, ws, ws.codes.as<uint32_t>(), n, plan.nwin, plan.c, ws.entries.as<uint2>());
+    } else {
+        ws.keys.ensure(tot * sizeof(uint64_t));
+        {
+            ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin, plan.nb,
+                               ws.keys.as<uint64_t>(), (uint32_t *)nullptr, (uint32_t)tb);
+        }
+        unsigned key_bits = 1;
+        while (((size_t)1 << key_bits) <= tb) key_bits++;
+        msm_sort_keys(ctx, ws, tot, key_bits);
     }
-    unsigned key_bits = 1;
-    while (((size_t)1 << key_bits) <= tb) key_bits++;
-    msm_sort_keys(ctx, ws, tot, key_bits);
     {
         ScopedKernelTimer kt(ctx, "msm_offsets_kernel", (double)tb, ctx->stream);
         hipLaunchKernelGGL(msm_offsets_kernel, dim3((unsigned)((tb + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ws.entries.as<uint2>(), tot, ws.offsets.as<uint32_t>(), tb);
+                           ws.entries.as<uint2>(), tot, win_total, plan.nwin, ws.offsets.as<uint32_t>(), tb);
     }
     ZK_HIP(hipGetLastError());
     // the exact entry count stays on the device (offsets[tb]); the accumulation grids are one resident round of waves and
@@ -696,7 +750,9 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     const unsigned grid = (unsigned)((nseg + 63) / 64);
     {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
-        hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        const bool pipe = (ctx->opt_acc_pipeline >> (FieldTraits<F>::g2 ? 1 : 0)) & 1;
+        if (pipe) hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), dim3(grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3(grid), dim3(64), 0, ctx->stream, a);
     }
     static_assert(sizeof(AccArgs<F>) <= sizeof(slot.acc_args), "MsmSlot::acc_args too small");
     memcpy(slot.acc_args, &a, sizeof a);
@@ -739,7 +795,13 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     const size_t nchunks = plan.nb / kk;
     const size_t tot = nchunks * plan.nwin;
     const int kk2 = 8;
-    slot.two_level_k = (ctx->opt_reduce_mode == 1 && kk >= 2 && nchunks >= 2 * (size_t)kk2) ? kk : 0;
+    // work-efficient form: mode 1 everywhere; mode 2 everywhere except the MSM whose reduction is the exposed tail of the proof
+    // (slot.last_of_proof, set by the caller): the others overlap the next accumulation, where work, not depth, is what costs
+    // default (3): mode 2 from 16-bit windows on (measured 128x128: 184.1 -> 182.5 ms; 32x32: no change; a 6,476-constraint proof
+    // 3.6 -> 4.8 ms with it, so small windows keep the short chain)
+    const bool efficient = ctx->opt_reduce_mode == 1 || (ctx->opt_reduce_mode == 2 && !slot.last_of_proof) ||
+                           (ctx->opt_reduce_mode == 3 && !slot.last_of_proof && slot.c >= 16);
+    slot.two_level_k = (efficient && kk >= 2 && nchunks >= 2 * (size_t)kk2) ? kk : 0;
     const size_t nout = (slot.two_level_k ? 2 : 1) * (size_t)plan.nwin;
     slot.red_a.ensure(tot * psz);
     slot.red_b.ensure(tot * psz);
