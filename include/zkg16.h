@@ -182,6 +182,15 @@ ZKG16_API int zkg16_circuit_matrix(size_t n, const uint64_t *a /* n*n, row-major
  * MatrixCircuit depend on n alone, so a caller that kept them from one zkg16_circuit_matrix call needs only this per request. */
 ZKG16_API int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *z, size_t n_assign);
 ZKG16_API int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit **out);
+/*   PrimeCircuit      src/arkworks/prime_snark/prime_circut.rs:92-146 (+ fermat_circut.rs, utils/hasher.rs, utils/modulo.rs): SHA-256 of
+ *                     x + j, the digest mod 2^20, three hashed Fermat bases, 20-step square-and-multiply with witnessed quotients.
+ *                     The SHA-256 / Boolean / comparison gadgets come from un-vendored crates upstream and are restated here:
+ *                     values (digests, modpows, satisfaction, verification) are checked, the constraint LAYOUT is unpinned.
+ * zkg16_prime_search = the handler's loop over check_if_next_is_prime (backend/prime_snark.rs:57-70). */
+ZKG16_API int zkg16_prime_search(uint64_t x, uint64_t i_max, uint64_t *j_out, uint32_t *prime_out, uint8_t digest_out[32], int *found);
+ZKG16_API int zkg16_prime_candidate(uint64_t x, uint64_t j, uint8_t digest_out[32], uint32_t *n_out, uint32_t bases_out[3],
+                          uint8_t r_bytes_out[32], int *is_prime);
+ZKG16_API int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out);
 ZKG16_API void zkg16_circuit_free(zkg16_circuit *c);
 ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]);
 ZKG16_API int zkg16_circuit_is_satisfied(const zkg16_circuit *c);

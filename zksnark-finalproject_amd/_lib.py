@@ -51,6 +51,9 @@ SIGNATURES = {
     "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),
     "zkg16_circuit_matrix_witness": (C.c_int, [sz, u64p, u64p, u64p, sz]),
     "zkg16_circuit_fibonacci": (C.c_int, [C.c_uint64, C.c_uint64, sz, C.POINTER(vp)]),
+    "zkg16_prime_search": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), u8p, C.POINTER(C.c_int)]),
+    "zkg16_prime_candidate": (C.c_int, [C.c_uint64, C.c_uint64, u8p, C.POINTER(C.c_uint32), u32p, u8p, C.POINTER(C.c_int)]),
+    "zkg16_circuit_prime": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "zkg16_circuit_free": (None, [vp]),
     "zkg16_circuit_dims": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
     "zkg16_circuit_is_satisfied": (C.c_int, [vp]),

@@ -11,14 +11,14 @@ from ._lib import Zkg16Error
 class SynthesizedCircuit:
     """num_instance (incl. the constant 1), num_witness, num_constraints, r1cs (dict of CSR triples), z (Montgomery)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, check_satisfied=False):
         lib = _lib.load()
         ni, nw, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
         nnz = (C.c_size_t * 3)()
         lib.zkg16_circuit_dims(handle, C.byref(ni), C.byref(nw), C.byref(nc), C.byref(nnz))
         self.num_instance, self.num_witness, self.num_constraints = ni.value, nw.value, nc.value
         self.num_vars = ni.value + nw.value
-        self.satisfied = bool(lib.zkg16_circuit_is_satisfied(handle)) if nc.value <= 200000 else None
+        self.satisfied = bool(lib.zkg16_circuit_is_satisfied(handle)) if (nc.value <= 200000 or check_satisfied) else None
         rp = [np.zeros(nc.value + 1, dtype=np.uint64) for _ in range(3)]
         col = [np.zeros(max(nnz[m], 1), dtype=np.uint32) for m in range(3)]
         cf = [np.zeros((max(nnz[m], 1), 4), dtype=np.uint64) for m in range(3)]
@@ -67,6 +67,46 @@ def fibonacci_circuit(a, b, steps):
     if rc:
         raise Zkg16Error(rc, "zkg16_circuit_fibonacci")
     return SynthesizedCircuit(h)
+
+
+def prime_search(x, i_max):
+    """The prime handler's native search (backend/prime_snark.rs:57-70): first j <= i_max whose hash(x + j) mod 2^20 passes the
+    Fermat test -> dict(found, j, prime, digest) (zkg16_prime_search)."""
+    j, p, found = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    digest = np.zeros(32, dtype=np.uint8)
+    rc = _lib.load().zkg16_prime_search(x, i_max, C.byref(j), C.byref(p), digest, C.byref(found))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_prime_search")
+    return dict(found=bool(found.value), j=j.value, prime=p.value, digest=bytes(digest))
+
+
+def prime_candidate(x, j):
+    """check_if_next_is_prime(x, j) natively -> dict(digest, n, bases, r_bytes, is_prime)."""
+    n, isp = C.c_uint32(0), C.c_int(0)
+    digest, rb = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+    bases = np.zeros(3, dtype=np.uint32)
+    rc = _lib.load().zkg16_prime_candidate(x, j, digest, C.byref(n), bases, rb, C.byref(isp))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_prime_candidate")
+    return dict(digest=bytes(digest), n=n.value, bases=[int(b) for b in bases], r_bytes=bytes(rb), is_prime=bool(isp.value))
+
+
+def prime_circuit(x, i_max_or_j, search=True):
+    """The reference's PrimeCircuit (C++ mirror).  search=True: as prove_prime — find the first prime candidate j <= i_max and
+    build its circuit (raises if none); search=False: the circuit of candidate j itself, as verify_prime rebuilds it."""
+    j = i_max_or_j
+    if search:
+        res = prime_search(x, i_max_or_j)
+        if not res["found"]:
+            raise ValueError("no prime candidate for x=%d within i=%d" % (x, i_max_or_j))
+        j = res["j"]
+    h = C.c_void_p()
+    rc = _lib.load().zkg16_circuit_prime(x, j, C.byref(h))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_prime")
+    c = SynthesizedCircuit(h, check_satisfied=True)
+    c.j = j
+    return c
 
 
 def poseidon_hash(elems_mont):

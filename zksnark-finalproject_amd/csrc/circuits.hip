@@ -397,6 +397,8 @@ Lc poseidon_hash_gadget(Circuit &cs, const std::vector<Lc> &elems) {
     return st[POSEIDON_CAP];
 }
 
+#include "prime_circuit.inc"
+
 }  // namespace
 
 struct zkg16_circuit {
@@ -452,6 +454,57 @@ int zkg16_circuit_fibonacci(uint64_t a, uint64_t b, size_t steps, zkg16_circuit 
     }
     cs.enforce_equal(fi, saved);
     *out = c;
+    return ZKG16_OK;
+}
+
+// The native search of the prime handler (backend/prime_snark.rs:57-70): the first j in [0, i_max] for which
+// hash(x + j) mod 2^20 passes the Fermat test with the three hashed bases (check_if_next_is_prime).
+int zkg16_prime_search(uint64_t x, uint64_t i_max, uint64_t *j_out, uint32_t *prime_out, uint8_t digest_out[32], int *found) {
+    if (!found) return ZKG16_ERR_BAD_ARG;
+    *found = 0;
+    for (uint64_t j = 0; j <= i_max; j++) {
+        const PrimeCandidate c = prime_candidate(x, j);
+        if (c.is_prime) {
+            *found = 1;
+            if (j_out) *j_out = j;
+            if (prime_out) *prime_out = c.n;
+            if (digest_out) memcpy(digest_out, c.digest, 32);
+            return ZKG16_OK;
+        }
+        if (j == UINT64_MAX) break;
+    }
+    return ZKG16_OK;
+}
+// one candidate natively: digest = SHA-256(le32(x + j)), n = digest mod 2^20, the three bases hash(r || k) mod n and the
+// Fermat verdict (tests compare these with hashlib / pow)
+int zkg16_prime_candidate(uint64_t x, uint64_t j, uint8_t digest_out[32], uint32_t *n_out, uint32_t bases_out[3], uint8_t r_bytes_out[32],
+                          int *is_prime) {
+    const PrimeCandidate c = prime_candidate(x, j);
+    if (digest_out) memcpy(digest_out, c.digest, 32);
+    if (n_out) *n_out = c.n;
+    if (bases_out) for (int k = 0; k < PRIME_K; k++) bases_out[k] = c.n >= 2 ? c.base[k] : 0;
+    if (r_bytes_out) memcpy(r_bytes_out, c.r_bytes, 32);
+    if (is_prime) *is_prime = c.is_prime ? 1 : 0;
+    return ZKG16_OK;
+}
+// PrimeCircuit::new(...) for the candidate at index j, as prove_prime builds it for the j it found and verify_prime
+// rebuilds it to recover the public inputs (prime_snark.rs:98-105, 170-193).  Instance: 1, x, the 256 digest bits.
+int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
+    if (!out) return ZKG16_ERR_BAD_ARG;
+    *out = nullptr;
+    const PrimeCandidate cand = prime_candidate(x, j);
+    if (cand.n < 2) return ZKG16_ERR_UNSUPPORTED;          // the reference's BigUint modpow panics on a modulus below 2
+    for (int k = 0; k < PRIME_K; k++)
+        if (cand.base[k] == 0) return ZKG16_ERR_UNSUPPORTED;  // base.inverse().unwrap() panics upstream
+    try {
+        std::unique_ptr<zkg16_circuit> c(new zkg16_circuit());
+        build_prime_circuit(c->add_segment(0), x, j, cand);
+        *out = c.release();
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    } catch (const std::exception &) {
+        return ZKG16_ERR_UNSUPPORTED;
+    }
     return ZKG16_OK;
 }
 

@@ -1,6 +1,7 @@
 """In-process mirrors of the reference's request handlers around the hot path (the callers of `Groth16::prove`):
     prove_matrix     src/arkworks/backend/matrix_proof.rs:94-166   (POST /api/matrix_prove/prove)
     prove_fibonacci  src/arkworks/backend/fibbonaci_handler.rs:98-145
+    prove_prime / verify_prime  src/arkworks/backend/prime_snark.rs:49-146, 165-206
 Same steps, same response fields: synthesize the circuit (host C++ mirror), per-request Groth16 setup (on the device,
 zkg16_setup), prove (zkg16_prove_resident), encode (wire.py).  The reference's HTTP layer (actix-web) is out of scope; the
 trapdoor and r, s come from Python's PRNG rather than arkworks' StdRng stream, so proofs are valid Groth16 proofs for the
@@ -11,7 +12,7 @@ import time
 import numpy as np
 
 from . import wire
-from .circuits import fibonacci_circuit, matrix_circuit
+from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_search
 from .workloads import R_MOD, g1_generator, g2_generator
 
 
@@ -98,6 +99,26 @@ def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
                 fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
+
+
+def prove_prime(dev, x, i, seed=7, keep_key=False):
+    """-> the reference's ProveOutput fields of the prime handler (prime_snark.rs:36-47): search j in 0..=i for the first
+    hash(x + j) mod 2^20 that passes the Fermat test, build PrimeCircuit for it, circuit-specific setup, prove."""
+    found = prime_search(x, i)
+    if not found["found"]:
+        return dict(proof="", j=0, num_constraints=0, num_variables=0, setup_time=0.0, proving_time=0.0, found_prime=False, prime_num="", vk="")
+    circ = prime_circuit(x, found["j"], search=False)
+    out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
+    return dict(proof=wire.encode_proof(out["proof"], out["inf"]), j=found["j"], num_constraints=circ.num_constraints,
+                num_variables=circ.num_vars, setup_time=out["setup_time"], proving_time=out["proving_time"], found_prime=True,
+                prime_num=str(found["prime"]), vk=wire.encode_vk(out["vk"]), satisfied=circ.satisfied, _detail=out, _circuit=circ)
+
+
+def verify_prime(vk, x, j, proof_b64):
+    """Mirror of verify_prime (prime_snark.rs:165-206): the verifier re-synthesizes PrimeCircuit for (x, j) to recover the
+    public inputs (x and the 256 digest bits), then checks the proof."""
+    circ = prime_circuit(x, j, search=False)
+    return verify_proof(vk, circ.public_inputs, proof_b64)
 
 
 def verify_proof(vk, public_inputs_mont, proof_b64):
