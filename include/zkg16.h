@@ -163,6 +163,19 @@ ZKG16_API int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[2
                  const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs,
                  const uint64_t proof[48], const uint8_t inf[3], int *ok);
 
+/* prepare_verifying_key (what the reference's handlers return as `pvk`: matrix_proof.rs:134-136, io.rs:62-77) and
+ * verify_with_processed_vk on such a key, both host-only.  alpha_beta = e(alpha, beta) as ark's Fq12 (six Fq2 in tower order,
+ * 72 u64 Montgomery limbs); *_neg_coeffs = the G2Prepared line coefficients of -gamma / -delta (*n_coeffs = 68 triples of Fq2 =
+ * 68 x 36 u64 each, caller-allocated).  ark-ec's formulas are restated (un-vendored crate): self-consistent and cross-checked
+ * against the plain verifier, byte parity with upstream unpinned.  Both verifiers reject proof points that are not on the curve
+ * or not in the prime-order subgroup (zkg16_point_check: group 1 = G1 / 12 limbs, 2 = G2 / 24 limbs). */
+ZKG16_API int zkg16_pvk_prepare(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t gamma_g2[24], const uint64_t delta_g2[24],
+                      uint64_t alpha_beta[72], uint64_t *gamma_neg_coeffs, uint64_t *delta_neg_coeffs, size_t *n_coeffs);
+ZKG16_API int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs, const uint64_t alpha_beta[72],
+                          const uint64_t *gamma_neg_coeffs, const uint64_t *delta_neg_coeffs, size_t n_coeffs,
+                          const uint64_t proof[48], const uint8_t inf[3], int *ok);
+ZKG16_API int zkg16_point_check(int group, const uint64_t *point, int *ok);
+
 /* prod_i e(P_i, Q_i) == 1 ?  Host-only (no ctx, no GPU).  g1: n x 12 limbs, g2: n x 24 limbs, flag bytes nullable.
  * flags: ZKG16_PAIRING_PLAIN_FINAL_EXP = final exponentiation as one plain power by (q^12-1)/r (slow cross-check of the
  * default Frobenius + |z|-chain path).  The building block of zkg16_verify; mirrors ark-ec's `Pairing::multi_pairing`

@@ -38,8 +38,10 @@ class _Pk(C.Structure):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        override = os.environ.get("ZKG16_ORACLE_LIB")         # tests/test_oracle_sanitize.py: the ASan/UBSan build
+        if not override:
+            build()
+        L = C.CDLL(override or _LIB_PATH)
         L.orc_banner.restype = C.c_char_p
         L.orc_set_threads.argtypes = [C.c_int]
         for f in ("fr", "fq"):

@@ -47,6 +47,9 @@ SIGNATURES = {
     "zkg16_scalar_mul_g1": (C.c_int, [u64p, u64p, u64p, C.POINTER(C.c_uint8)]),
     "zkg16_scalar_mul_g2": (C.c_int, [u64p, u64p, u64p, C.POINTER(C.c_uint8)]),
     "zkg16_pairing_check": (C.c_int, [u64p, u8p, u64p, u8p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
+    "zkg16_pvk_prepare": (C.c_int, [u64p, u64p, u64p, u64p, u64p, u64p, u64p, C.POINTER(sz)]),
+    "zkg16_verify_prepared": (C.c_int, [u64p, sz, vp, u64p, u64p, u64p, sz, u64p, u8p, C.POINTER(C.c_int)]),
+    "zkg16_point_check": (C.c_int, [C.c_int, u64p, C.POINTER(C.c_int)]),
     "zkg16_verify": (C.c_int, [u64p, u64p, u64p, u64p, u64p, sz, vp, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),
     "zkg16_circuit_matrix_witness": (C.c_int, [sz, u64p, u64p, u64p, sz]),

@@ -240,6 +240,144 @@ bool pairing_product_is_one(std::vector<MillerPair> &pairs, bool plain_final_exp
     return fq12_is_one(plain_final_exp ? fq12_pow(f, FINAL_EXP, FINAL_EXP_LIMBS) : final_exp_fast(f));
 }
 
+// ------------------------------------------------------------------------------------------------ prepared keys
+// ark-ec 0.4.2 models/bls12/g2.rs `G2Prepared::from(G2Affine)` and `Bls12::multi_miller_loop` / `ell`, restated: the
+// reference ships `PreparedVerifyingKey` (io.rs:62-77: encode_pvk; matrix_proof.rs:134-136), whose serialization holds
+// e(alpha, beta) in ark's Fq12 tower and, for -gamma and -delta, the 68 line-coefficient triples of the Miller loop over
+// X = 0xd201000000010000 (63 doublings + 5 additions) in exactly ark's scaling (homogeneous projective, halvings by 2^-1).
+struct EllCoeff { Fq2 c0, c1, c2; };
+struct G2Prepared {
+    std::vector<EllCoeff> ell;
+    bool infinity = true;
+};
+const Fq &two_inv() {
+    static const Fq v = [] {
+        Fq c = Fq::zero();
+        c.l[0] = 2;
+        return fp_inv(fp_to_mont(c));
+    }();
+    return v;
+}
+const Fq2 &twist_b() {       // G2 COEFF_B = 4 (1 + u)
+    static const Fq2 v = [] {
+        Fq c = Fq::zero();
+        c.l[0] = 4;
+        const Fq m = fp_to_mont(c);
+        return Fq2{m, m};
+    }();
+    return v;
+}
+// G2HomProjective::double_in_place (M twist): returns (i, 3j, -h)
+EllCoeff ark_double(G2Proj &r) {
+    const Fq2 a = fq2_scale(f_mul(r.x, r.y), two_inv());
+    const Fq2 b = f_sqr(r.y);
+    const Fq2 c = f_sqr(r.z);
+    const Fq2 e = f_mul(twist_b(), f_add(f_dbl(c), c));
+    const Fq2 f = f_add(f_dbl(e), e);
+    const Fq2 g = fq2_scale(f_add(b, f), two_inv());
+    const Fq2 h = f_sub(f_sqr(f_add(r.y, r.z)), f_add(b, c));
+    const Fq2 i = f_sub(e, b);
+    const Fq2 j = f_sqr(r.x);
+    const Fq2 e2 = f_sqr(e);
+    r.x = f_mul(a, f_sub(b, f));
+    r.y = f_sub(f_sqr(g), f_add(f_dbl(e2), e2));
+    r.z = f_mul(b, h);
+    return EllCoeff{i, f_add(f_dbl(j), j), f_neg(h)};
+}
+// G2HomProjective::add_in_place (M twist): returns (j, -theta, lambda)
+EllCoeff ark_add(G2Proj &r, const G2Affine &q) {
+    const Fq2 theta = f_sub(r.y, f_mul(q.y, r.z));
+    const Fq2 lambda = f_sub(r.x, f_mul(q.x, r.z));
+    const Fq2 c = f_sqr(theta), d = f_sqr(lambda);
+    const Fq2 e = f_mul(lambda, d), f = f_mul(r.z, c), g = f_mul(r.x, d);
+    const Fq2 h = f_sub(f_add(e, f), f_dbl(g));
+    const Fq2 ry = r.y;
+    r.x = f_mul(lambda, h);
+    r.y = f_sub(f_mul(theta, f_sub(g, h)), f_mul(e, ry));
+    r.z = f_mul(r.z, e);
+    const Fq2 j = f_sub(f_mul(theta, q.x), f_mul(lambda, q.y));
+    return EllCoeff{j, f_neg(theta), lambda};
+}
+G2Prepared g2_prepare(const G2Affine &q) {
+    G2Prepared p;
+    if (q.is_inf()) return p;
+    p.infinity = false;
+    G2Proj r{q.x, q.y, Fq2::one()};
+    for (int i = 62; i >= 0; i--) {          // BitIteratorBE::new(X).skip(1)
+        p.ell.push_back(ark_double(r));
+        if ((Z_ABS >> i) & 1) p.ell.push_back(ark_add(r, q));
+    }
+    return p;
+}
+// Bls12::ell (M twist): c2 *= p.y, c1 *= p.x, f.mul_by_014(c0, c1, c2) — in the flat basis: c0 + c1 w^2 + c2 w^3
+void ark_ell(Fq12 &f, const EllCoeff &c, const G1Affine &p) { f = fq12_mul(f, line_value(c.c0, fq2_scale(c.c1, p.x), fq2_scale(c.c2, p.y))); }
+// Bls12::multi_miller_loop over (G1 point, prepared G2) pairs, with the conjugation for the negative loop count
+Fq12 ark_multi_miller_loop(const std::vector<std::pair<G1Affine, const G2Prepared *>> &all) {
+    std::vector<std::pair<G1Affine, const G2Prepared *>> pairs;
+    for (const auto &pr : all)
+        if (!pr.first.is_inf() && !pr.second->infinity) pairs.push_back(pr);
+    Fq12 f = fq12_one();
+    size_t k = 0;
+    for (int i = 62; i >= 0; i--) {
+        f = fq12_mul(f, f);
+        for (const auto &pr : pairs) ark_ell(f, pr.second->ell[k], pr.first);
+        k++;
+        if ((Z_ABS >> i) & 1) {
+            for (const auto &pr : pairs) ark_ell(f, pr.second->ell[k], pr.first);
+            k++;
+        }
+    }
+    return fq12_conj(f);                     // X_IS_NEGATIVE: cyclotomic_inverse_in_place
+}
+bool fq12_eq(const Fq12 &a, const Fq12 &b) {
+    for (int k = 0; k < 6; k++)
+        if (!(a.c[k] == b.c[k])) return false;
+    return true;
+}
+// ark's tower order: Fq12 = c0 + c1 w over Fq6 = Fq2[v]/(v^3 - xi) with v = w^2:  (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2)
+// = flat coefficients of (1, w^2, w^4, w, w^3, w^5)
+const int TOWER_ORDER[6] = {0, 2, 4, 1, 3, 5};
+void fq12_to_abi(const Fq12 &a, uint64_t out[72]) {
+    for (int k = 0; k < 6; k++) memcpy(out + 12 * k, &a.c[TOWER_ORDER[k]], sizeof(Fq2));
+}
+Fq12 fq12_from_abi(const uint64_t in[72]) {
+    Fq12 a;
+    for (int k = 0; k < 6; k++) memcpy(&a.c[TOWER_ORDER[k]], in + 12 * k, sizeof(Fq2));
+    return a;
+}
+const size_t ELL_COUNT = 68;
+void prepared_to_abi(const G2Prepared &p, uint64_t *out /* 68 x 36 */) {
+    for (size_t i = 0; i < p.ell.size(); i++) memcpy(out + 36 * i, &p.ell[i], sizeof(EllCoeff));
+}
+G2Prepared prepared_from_abi(const uint64_t *in, size_t n) {
+    G2Prepared p;
+    p.infinity = n == 0;
+    p.ell.resize(n);
+    for (size_t i = 0; i < n; i++) memcpy(&p.ell[i], in + 36 * i, sizeof(EllCoeff));
+    return p;
+}
+G2Affine g2_neg(const G2Affine &p) { return p.is_inf() ? p : G2Affine{p.x, f_neg(p.y)}; }
+
+// ---- membership: on the curve and in the prime-order subgroup ([r] P = O) — what ark's deserialize_compressed validates
+const uint32_t *r_limbs() {
+    static uint32_t l[8];
+    static bool init = [] { for (int i = 0; i < 8; i++) l[i] = FrP::mod(i); return true; }();
+    (void)init;
+    return l;
+}
+bool g1_valid(const G1Affine &p) {
+    if (p.is_inf()) return true;
+    Fq c = Fq::zero();
+    c.l[0] = 4;
+    if (!(fp_sqr(p.y) == fp_add(fp_mul(fp_sqr(p.x), p.x), fp_to_mont(c)))) return false;
+    return xyzz_mul(G1XYZZ::from_affine(p), r_limbs()).is_inf();
+}
+bool g2_valid(const G2Affine &p) {
+    if (p.is_inf()) return true;
+    if (!(f_sqr(p.y) == f_add(f_mul(f_sqr(p.x), p.x), twist_b()))) return false;
+    return xyzz_mul(G2XYZZ::from_affine(p), r_limbs()).is_inf();
+}
+
 G1Affine g1_neg(const G1Affine &p) { return p.is_inf() ? p : G1Affine{p.x, fp_neg(p.y)}; }
 
 template <class A>
@@ -308,6 +446,9 @@ int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const 
     const G1Affine X = xyzz_to_affine(acc);
     const G1Affine A = load_pt<G1Affine>(proof, inf[0]), C = load_pt<G1Affine>(proof + 36, inf[2]);
     const G2Affine B = load_pt<G2Affine>(proof + 12, inf[1]);
+    // ark's Proof::deserialize_compressed validates curve and subgroup membership before the handler ever verifies
+    // (io.rs:53-60); a pairing on arbitrary coordinates is not a verification
+    if (!g1_valid(A) || !g2_valid(B) || !g1_valid(C)) { *ok = 0; return ZKG16_OK; }
     try {
         std::vector<MillerPair> pairs(4);
         pairs[0].p = A; pairs[0].q = B;
@@ -318,6 +459,65 @@ int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const 
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
+    return ZKG16_OK;
+}
+
+// prepare_verifying_key (ark-groth16 verifier.rs): e(alpha, beta) and the prepared -gamma, -delta.  alpha_beta: 72 u64 = the six
+// Fq2 of ark's Fq12 tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2), Montgomery limbs; *_coeffs: 68 x 36 u64 (three Fq2
+// per Miller-loop line, in loop order).  The bytes the reference puts on the wire are wire.encode_pvk's.
+int zkg16_pvk_prepare(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const uint64_t gamma_g2[24], const uint64_t delta_g2[24],
+                      uint64_t alpha_beta[72], uint64_t *gamma_neg_coeffs, uint64_t *delta_neg_coeffs, size_t *n_coeffs) {
+    if (!alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !alpha_beta || !gamma_neg_coeffs || !delta_neg_coeffs || !n_coeffs) return ZKG16_ERR_BAD_ARG;
+    try {
+        const G1Affine a = load_pt<G1Affine>(alpha_g1, 0);
+        const G2Prepared b = g2_prepare(load_pt<G2Affine>(beta_g2, 0));
+        const G2Prepared g = g2_prepare(g2_neg(load_pt<G2Affine>(gamma_g2, 0))), d = g2_prepare(g2_neg(load_pt<G2Affine>(delta_g2, 0)));
+        if (g.ell.size() != ELL_COUNT || d.ell.size() != ELL_COUNT) return ZKG16_ERR_BAD_ARG;      // gamma / delta at infinity: not a key
+        fq12_to_abi(final_exp_fast(ark_multi_miller_loop({{a, &b}})), alpha_beta);
+        prepared_to_abi(g, gamma_neg_coeffs);
+        prepared_to_abi(d, delta_neg_coeffs);
+        *n_coeffs = ELL_COUNT;
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    }
+    return ZKG16_OK;
+}
+
+// Groth16::verify_with_processed_vk (verifier.rs), restated: prepared_inputs = gamma_abc[0] + sum z_i gamma_abc[i];
+// final_exponentiation(multi_miller_loop([(A, B), (prepared_inputs, -gamma prepared), (C, -delta prepared)])) == e(alpha, beta).
+// Proof points are checked for curve and subgroup membership first (ark's deserialization does).
+int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs, const uint64_t alpha_beta[72],
+                          const uint64_t *gamma_neg_coeffs, const uint64_t *delta_neg_coeffs, size_t n_coeffs,
+                          const uint64_t proof[48], const uint8_t inf[3], int *ok) {
+    if (!gamma_abc_g1 || num_instance == 0 || (!public_inputs && num_instance > 1) || !alpha_beta || !gamma_neg_coeffs || !delta_neg_coeffs ||
+        n_coeffs != ELL_COUNT || !proof || !inf || !ok)
+        return ZKG16_ERR_BAD_ARG;
+    try {
+        G1XYZZ acc = G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1, 0));
+        for (size_t i = 1; i < num_instance; i++) {
+            Fr z;
+            memcpy(&z, public_inputs + 4 * (i - 1), sizeof z);
+            const Fr zc = fp_from_mont(z);
+            G1XYZZ t = xyzz_mul(G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1 + 12 * i, 0)), zc.l);
+            xyzz_add(acc, t);
+        }
+        const G1Affine X = xyzz_to_affine(acc);
+        const G1Affine A = load_pt<G1Affine>(proof, inf[0]), C = load_pt<G1Affine>(proof + 36, inf[2]);
+        const G2Affine B = load_pt<G2Affine>(proof + 12, inf[1]);
+        if (!g1_valid(A) || !g2_valid(B) || !g1_valid(C)) { *ok = 0; return ZKG16_OK; }
+        const G2Prepared bp = g2_prepare(B), gp = prepared_from_abi(gamma_neg_coeffs, n_coeffs), dp = prepared_from_abi(delta_neg_coeffs, n_coeffs);
+        const Fq12 test = final_exp_fast(ark_multi_miller_loop({{A, &bp}, {X, &gp}, {C, &dp}}));
+        *ok = fq12_eq(test, fq12_from_abi(alpha_beta)) ? 1 : 0;
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    }
+    return ZKG16_OK;
+}
+
+// curve + prime-order-subgroup membership of one affine point (group: 1 = G1, 2 = G2); *ok = 1 iff both hold
+int zkg16_point_check(int group, const uint64_t *point, int *ok) {
+    if (!point || !ok || (group != 1 && group != 2)) return ZKG16_ERR_BAD_ARG;
+    *ok = (group == 1 ? g1_valid(load_pt<G1Affine>(point, 0)) : g2_valid(load_pt<G2Affine>(point, 0))) ? 1 : 0;
     return ZKG16_OK;
 }
 

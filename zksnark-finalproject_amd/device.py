@@ -331,3 +331,44 @@ def scalar_mul(group, base, k_canonical):
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     return out, int(inf.value)
+
+
+def point_check(group, point):
+    """Curve + prime-order-subgroup membership of one affine point (zkg16_point_check; host-only)."""
+    lib = _lib.load()
+    ok = C.c_int(0)
+    rc = lib.zkg16_point_check(1 if group == "g1" else 2, _u64(point).reshape(-1), C.byref(ok))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return bool(ok.value)
+
+
+def pvk_prepare(vk):
+    """prepare_verifying_key (host-only zkg16_pvk_prepare): vk dict -> the same dict plus alpha_beta (72 u64: ark's Fq12 tower
+    order) and gamma_neg_pc / delta_neg_pc (68 x 36 u64 line coefficients each)."""
+    lib = _lib.load()
+    ab = np.zeros(72, dtype=np.uint64)
+    g = np.zeros(68 * 36, dtype=np.uint64)
+    d = np.zeros(68 * 36, dtype=np.uint64)
+    n = C.c_size_t(0)
+    rc = lib.zkg16_pvk_prepare(_u64(vk["alpha_g1"]), _u64(vk["beta_g2"]), _u64(vk["gamma_g2"]), _u64(vk["delta_g2"]), ab, g, d, C.byref(n))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    out = dict(vk)
+    out.update(alpha_beta=ab, gamma_neg_pc=g.reshape(n.value, 36), delta_neg_pc=d.reshape(n.value, 36))
+    return out
+
+
+def verify_prepared(pvk, public_inputs_mont, proof48, inf3):
+    """Groth16::verify_with_processed_vk on a prepared key (host-only zkg16_verify_prepared)."""
+    lib = _lib.load()
+    gabc = _u64(pvk["gamma_abc_g1"]).reshape(-1, 12)
+    pub = _u64(public_inputs_mont).reshape(-1, 4)
+    assert pub.shape[0] == gabc.shape[0] - 1
+    g, d = _u64(pvk["gamma_neg_pc"]).reshape(-1, 36), _u64(pvk["delta_neg_pc"]).reshape(-1, 36)
+    ok = C.c_int(0)
+    rc = lib.zkg16_verify_prepared(gabc, gabc.shape[0], _ptr(pub) if pub.size else None, _u64(pvk["alpha_beta"]), g, d, g.shape[0],
+                                   _u64(proof48), np.ascontiguousarray(inf3, dtype=np.uint8), C.byref(ok))
+    if rc != 0:
+        raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
+    return bool(ok.value)

@@ -88,8 +88,8 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
                 # the reference counts matrix_mul twice (outer cs + circuit: matrix_proof.rs:108,150,160)
                 num_constraints=circ.num_constraints + 2 * size ** 3, num_constraints_circuit=circ.num_constraints,
                 num_variables=circ.num_instance, proof=wire.encode_proof(out["proof"], out["inf"]),
-                # the reference returns the *prepared* key here (encode_pvk, io.rs:53-60); see wire.vk_serialize_compressed
-                vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
+                # the reference returns the prepared key (encode_pvk, io.rs:62-68); the plain key is kept beside it
+                pvk=wire.encode_pvk(out["vk"]), vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
 
 
 def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
@@ -98,7 +98,8 @@ def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
-                fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], vk=wire.encode_vk(out["vk"]), _detail=out, _circuit=circ)
+                fib_number=[wire.encode_hash(x) for x in circ.public_inputs][-1], pvk=wire.encode_pvk(out["vk"]), vk=wire.encode_vk(out["vk"]),
+                _detail=out, _circuit=circ)
 
 
 def prove_prime(dev, x, i, seed=7, keep_key=False):
@@ -111,7 +112,8 @@ def prove_prime(dev, x, i, seed=7, keep_key=False):
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), j=found["j"], num_constraints=circ.num_constraints,
                 num_variables=circ.num_vars, setup_time=out["setup_time"], proving_time=out["proving_time"], found_prime=True,
-                prime_num=str(found["prime"]), vk=wire.encode_vk(out["vk"]), satisfied=circ.satisfied, _detail=out, _circuit=circ)
+                prime_num=str(found["prime"]), pvk=wire.encode_pvk(out["vk"]), vk=wire.encode_vk(out["vk"]), satisfied=circ.satisfied,
+                _detail=out, _circuit=circ)
 
 
 def verify_prime(vk, x, j, proof_b64):
@@ -125,10 +127,15 @@ def verify_proof(vk, public_inputs_mont, proof_b64):
     """Mirror of the verify handlers (matrix_proof.rs:183-205, fibbonaci_handler.rs:118-145): decode the base64 compressed
     proof (and key, when given as the base64 string the prove mirrors return), check the Groth16 equation with the host
     verifier (zkg16_verify) -> {valid, verifying_time}."""
-    from .device import verify
+    from .device import verify, verify_prepared
     t0 = time.perf_counter()
-    if isinstance(vk, str):
-        vk = wire.decode_vk(vk)
-    proof, inf = wire.decode_proof(proof_b64)
-    ok = verify(vk, public_inputs_mont, proof, inf)
+    try:
+        if isinstance(vk, str):
+            raw = __import__("base64").standard_b64decode(vk)
+            n = int.from_bytes(raw[336:344], "little")
+            vk = wire.pvk_deserialize_compressed(raw) if len(raw) > 344 + 48 * n else wire.vk_deserialize_compressed(raw)
+        proof, inf = wire.decode_proof(proof_b64)
+    except ValueError:                  # the reference's decode_proof / decode_pvk return None and the handler answers invalid
+        return dict(valid=False, verifying_time=time.perf_counter() - t0)
+    ok = verify_prepared(vk, public_inputs_mont, proof, inf) if "alpha_beta" in vk else verify(vk, public_inputs_mont, proof, inf)
     return dict(valid=bool(ok), verifying_time=time.perf_counter() - t0)

@@ -76,25 +76,46 @@ def _sqrt_fq2(a0, a1):
     return None
 
 
-def g1_decompress(b):
-    assert len(b) == 48 and b[0] & 0x80, "not a compressed G1 point"
+def _subgroup_check(group, limbs):
+    """ark's deserialize_compressed validates: the point must lie in the prime-order subgroup (host-side zkg16_point_check)."""
+    from .device import point_check
+    if not point_check(group, limbs):
+        raise ValueError("%s point is not in the prime-order subgroup" % group)
+
+
+def g1_decompress(b, validate=True):
+    """Strict, as `G1Affine::deserialize_compressed`: canonical x (< q), a clean infinity encoding, on the curve, in the subgroup."""
+    if len(b) != 48 or not b[0] & 0x80:
+        raise ValueError("not a compressed G1 point")
     if b[0] & 0x40:
+        if b[0] != 0xC0 or any(b[1:]):
+            raise ValueError("non-canonical encoding of the point at infinity")
         return np.zeros(12, dtype=np.uint64), 1
     x = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:], "big")
+    if x >= Q:
+        raise ValueError("x coordinate is not reduced")
     y = _sqrt_fq((x * x * x + 4) % Q)
     if y is None:
         raise ValueError("x not on curve")
     if (y > (Q - y) % Q) != bool(b[0] & 0x20):
         y = (Q - y) % Q
-    return np.concatenate([_fq_mont(x), _fq_mont(y)]), 0
+    out = np.concatenate([_fq_mont(x), _fq_mont(y)])
+    if validate:
+        _subgroup_check("g1", out)
+    return out, 0
 
 
-def g2_decompress(b):
-    assert len(b) == 96 and b[0] & 0x80, "not a compressed G2 point"
+def g2_decompress(b, validate=True):
+    if len(b) != 96 or not b[0] & 0x80:
+        raise ValueError("not a compressed G2 point")
     if b[0] & 0x40:
+        if b[0] != 0xC0 or any(b[1:]):
+            raise ValueError("non-canonical encoding of the point at infinity")
         return np.zeros(24, dtype=np.uint64), 1
     x1 = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:48], "big")
     x0 = int.from_bytes(b[48:], "big")
+    if x0 >= Q or x1 >= Q:
+        raise ValueError("x coordinate is not reduced")
     # x^3 + 4(1 + u)
     a0 = (x0 * x0 - x1 * x1) % Q
     a1 = 2 * x0 * x1 % Q
@@ -106,7 +127,10 @@ def g2_decompress(b):
     y0, y1 = s
     if ((y1, y0) > ((-y1) % Q, (-y0) % Q)) != bool(b[0] & 0x20):
         y0, y1 = (-y0) % Q, (-y1) % Q
-    return np.concatenate([_fq_mont(x0), _fq_mont(x1), _fq_mont(y0), _fq_mont(y1)]), 0
+    out = np.concatenate([_fq_mont(x0), _fq_mont(x1), _fq_mont(y0), _fq_mont(y1)])
+    if validate:
+        _subgroup_check("g2", out)
+    return out, 0
 
 
 def proof_serialize_compressed(proof48, inf3):
@@ -116,7 +140,8 @@ def proof_serialize_compressed(proof48, inf3):
 
 
 def proof_deserialize_compressed(b):
-    assert len(b) == 192
+    if len(b) != 192:
+        raise ValueError("a compressed proof is 192 bytes")
     a, ia = g1_decompress(b[:48])
     bb, ib = g2_decompress(b[48:144])
     c, ic = g1_decompress(b[144:])
@@ -146,9 +171,7 @@ def decode_hash(s):
 def vk_serialize_compressed(vk):
     """VerifyingKey -> ark `CanonicalSerialize` compressed bytes: alpha_g1 (48) | beta_g2 (96) | gamma_g2 (96) | delta_g2 (96) |
     len(gamma_abc_g1) as u64 LE | gamma_abc_g1 (48 each)   (ark-groth16 data_structures.rs field order; Vec = u64 length
-    prefix).  The reference ships the *prepared* key (`encode_pvk`, io.rs:53-60): that additionally holds e(alpha, beta) in
-    arkworks' Fq12 tower and the two G2Prepared line-coefficient vectors, whose bytes depend on upstream-internal formula
-    choices that cannot be pinned offline — not produced here; a prepared key is recomputable from these bytes."""
+    prefix).  The reference ships the *prepared* key: pvk_serialize_compressed below."""
     gabc = np.asarray(vk["gamma_abc_g1"], dtype=np.uint64).reshape(-1, 12)
     out = g1_compress(vk["alpha_g1"], 0) + g2_compress(vk["beta_g2"], 0) + g2_compress(vk["gamma_g2"], 0) + g2_compress(vk["delta_g2"], 0)
     out += len(gabc).to_bytes(8, "little")
@@ -174,3 +197,67 @@ def encode_vk(vk):
 
 def decode_vk(s):
     return vk_deserialize_compressed(base64.standard_b64decode(s))
+
+
+# ---- PreparedVerifyingKey (what the reference's handlers return: encode_pvk, io.rs:62-77; matrix_proof.rs:134-136)
+# ark-groth16 0.4 data_structures.rs: PreparedVerifyingKey { vk, alpha_g1_beta_g2: Fq12, gamma_g2_neg_pc: G2Prepared, delta_g2_neg_pc: G2Prepared },
+# derived CanonicalSerialize = the fields in order.  Fq12 = 12 base-field elements, each 48 bytes little-endian canonical, in
+# tower order; G2Prepared { ell_coeffs: Vec<(Fq2, Fq2, Fq2)>, infinity: bool } = u64 LE length, 6 x 48 bytes per triple, 1 byte.
+# The coefficient VALUES follow ark-ec's line-function formulas as restated in csrc/verify.hip (un-vendored crate): the layout is
+# the published one, byte parity with a real arkworks pvk is unpinned (no fixture in the reference, no Rust toolchain here).
+def _fq_le(limbs6):
+    return _fq(limbs6).to_bytes(48, "little")
+
+
+def _fq_from_le(b):
+    v = int.from_bytes(b, "little")
+    if v >= Q:
+        raise ValueError("field element is not reduced")
+    return _fq_mont(v)
+
+
+def _prepared_bytes(coeffs):
+    c = np.asarray(coeffs, dtype=np.uint64).reshape(-1, 36)
+    out = len(c).to_bytes(8, "little")
+    for row in c:
+        out += b"".join(_fq_le(row[6 * k:6 * k + 6]) for k in range(6))
+    return out + b"\x00"                     # infinity = false
+
+
+def pvk_serialize_compressed(pvk):
+    """pvk: device.pvk_prepare(vk) -> bytes."""
+    ab = np.asarray(pvk["alpha_beta"], dtype=np.uint64)
+    return (vk_serialize_compressed(pvk) + b"".join(_fq_le(ab[6 * k:6 * k + 6]) for k in range(12)) +
+            _prepared_bytes(pvk["gamma_neg_pc"]) + _prepared_bytes(pvk["delta_neg_pc"]))
+
+
+def pvk_deserialize_compressed(b):
+    n = int.from_bytes(b[336:344], "little")
+    off = 344 + 48 * n
+    pvk = vk_deserialize_compressed(b[:off])
+    pvk["alpha_beta"] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(12)])
+    off += 576
+    for name in ("gamma_neg_pc", "delta_neg_pc"):
+        m = int.from_bytes(b[off:off + 8], "little")
+        off += 8
+        rows = np.zeros((m, 36), dtype=np.uint64)
+        for i in range(m):
+            rows[i] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(6)])
+            off += 288
+        if b[off] not in (0, 1) or (b[off] == 1) != (m == 0):
+            raise ValueError("inconsistent G2Prepared infinity flag")
+        off += 1
+        pvk[name] = rows
+    if off != len(b):
+        raise ValueError("trailing bytes after the prepared verifying key")
+    return pvk
+
+
+def encode_pvk(vk):
+    """VerifyingKey dict -> prepare_verifying_key -> serialize_compressed -> base64 (io.rs:62-68)."""
+    from .device import pvk_prepare
+    return base64.standard_b64encode(pvk_serialize_compressed(pvk_prepare(vk))).decode()
+
+
+def decode_pvk(s):
+    return pvk_deserialize_compressed(base64.standard_b64decode(s))
