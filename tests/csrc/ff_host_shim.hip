@@ -109,10 +109,16 @@ extern "C" void ht_fru_op(int op, const uint32_t *a, const uint32_t *b, uint32_t
         case 2: r = fru_mul(x, y); break;
         case 3: r = fru_mul(fru_sub_2r(x, y), y); break;                    // (a - b) b with the un-reduced difference (< 4r)
         case 4: st(o, fru_mul_to_sat(x, fru_repack(sb))); return;           // store path: U-form times a saturated-form factor
-        case 5: r = fru_mul(fru_repack(sa), fru_mul(fru_repack(sb), fru_c271())); break;     // coset load path: x g
-        case 6: {   // fused point-wise load path of the witness map's seventh transform: (a*b - b) * zc' with zc = a * 2^271 (zinv := a)
-            const Fr two15 = fp_to_mont([] { Fr c = Fr::zero(); c.l[0] = 1u << 15; return c; }());
-            const FrU zc = fru_repack(fp_mul(sa, two15));
+        case 5: {   // coset load path: x times a table entry scaled by 2^10 (one product = full conversion)
+            const Fr two10 = fp_to_mont([] { Fr c = Fr::zero(); c.l[0] = 1u << 10; return c; }());
+            r = fru_mul(fru_repack(sa), fru_repack(fp_mul(sb, two10)));
+            break;
+        }
+        case 7: r = fru_repack(sa); break;       // plain load: the stored limbs taken as the unsaturated form of x 2^-5
+        case 6: {   // fused point-wise load path of the witness map's seventh transform: (a*b - b) * zc with zc = a * 2^266 (zinv := a):
+                    // the result is the value times 2^-5 in the unsaturated form, exactly what a plain (conversion-free) load leaves
+            const Fr two10 = fp_to_mont([] { Fr c = Fr::zero(); c.l[0] = 1u << 10; return c; }());
+            const FrU zc = fru_repack(fp_mul(sa, two10));
             const FrU xb = fru_mul(fru_repack(sa), fru_repack(sb));
             const FrU c = fru_mul(fru_repack(sb), fru_one_sat());
             r = fru_mul(fru_sub_2r(xb, c), zc);

@@ -1,28 +1,48 @@
-"""Per-rank time of a sharded proof (development probe): one GPU plays rank 0 of G for G = 1, 2, 4, 8.
-   python tools/shard_timing.py [matrix_n]"""
+"""Per-rank time of one sharded proof under zkg16_shard_plan's rank roles, measured on ONE GPU that plays every rank in turn
+(development probe; no collective involved: the exchange is one 77-word all_gather, ~0.1 ms):
+   python tools/shard_timing.py [matrix_n] [G,G,...]
+For each G: the plan the cost model picks (k ranks run the witness map), the plan with k forced to G (round 1's equal split),
+and per rank the time of zkg16_prove_partial.  The slowest rank is the proof's time; speed-up = single-GPU time / that."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import bench
 from zksnark_finalproject_amd import Device
-from zksnark_finalproject_amd.circuits import matrix_circuit
+from zksnark_finalproject_amd.device import shard_plan
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 dev = Device(0)
-c = matrix_circuit(np.ones((n, n), dtype=np.uint64), np.ones((n, n), dtype=np.uint64))
-shp = dict(num_vars=c.num_vars, num_instance=c.num_instance, domain=c.domain)
-pk = bench.make_key(dev, c.r1cs, shp, seed=1)
-rh, wh = dev.r1cs_load(c.r1cs, c.num_vars), dev.witness_load(c.z)
-rng = np.random.default_rng(5)
-r, s = bench.rand_fr_mont(rng), bench.rand_fr_mont(rng)
-for G in (1, 2, 4, 8):
-    for k in sorted({0, G - 1}):
-        ph = dev.pk_load(pk, c.num_instance, shard_index=k, shard_count=G)
-        for _ in range(3):
-            dev.prove_partial(ph, rh, wh, r, s)
-        t0 = time.perf_counter()
-        for _ in range(10):
-            dev.prove_partial(ph, rh, wh, r, s)
-        dt = (time.perf_counter() - t0) / 10
-        print("n=%d shard %d of %d: %.2f ms per partial proof  %s" % (n, k, G, dt * 1e3, {a: round(b, 2) for a, b in dev.last_timings().items() if a in ("witness_map", "msm_sort", "total_wall")}), flush=True)
-        dev.pk_free(ph)
+trap, g1, g2 = bench.draw_key_inputs(7)
+c, _, desc = bench.synthesize("matrix", n)
+rh = dev.r1cs_load(c.r1cs, c.num_vars)
+full, vk = dev.setup_resident(rh, c.num_instance, trap, g1, g2)
+wh = dev.witness_load(c.z)
+r, s = bench.fr_mont(12345), bench.fr_mont(67890)
+reps = 3 if n >= 100 else 8
+print(desc, flush=True)
+single = None
+for G in Gs:
+    for force in ([0] if G == 1 else [0, G]):
+        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force)
+        worst = 0.0
+        per_rank = []
+        seen = {}
+        for i, (z_lo, z_hi, h_lo, h_hi, blind) in enumerate(plan):
+            sig = (z_hi - z_lo, h_hi - h_lo, blind)
+            if sig in seen and G > 2:          # ranks with the same amount of work: measure one of them
+                per_rank.append(seen[sig])
+                continue
+            sh = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)
+            dev.prove_partial(sh, rh, wh, r, s)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dev.prove_partial(sh, rh, wh, r, s)
+            dt = (time.perf_counter() - t0) / reps * 1e3
+            dev.pk_free(sh)
+            seen[sig] = dt
+            per_rank.append(dt)
+        worst = max(per_rank)
+        if G == 1:
+            single = worst
+        print("n=%d G=%d witness-map ranks k=%d%s: per-rank ms %s -> slowest %.2f ms, speed-up %.2fx" %
+              (n, G, k, " (forced: equal split)" if force else " (cost model)", [round(x, 2) for x in per_rank], worst, single / worst), flush=True)

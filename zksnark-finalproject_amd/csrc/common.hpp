@@ -81,6 +81,11 @@ struct NttTables {          // per domain size, built on device on first use
     DevBuf wu;              // the same in the unsaturated form (36 B per entry); only built for N > 2^22
     DevBuf g;               // g[i]  = 7^i                   (coset fft pre-multiply)
     DevBuf gi;              // gi[i] = 7^-i * N^-1           (coset ifft post-multiply)
+    // the same two tables for the unsaturated kernels with the form conversion folded in (built on first use): a load there
+    // skips the conversion product, which leaves a factor 2^-5 per pass behind; g_u = 2^10 g (its product is a full
+    // conversion), gi_u = 2^(5 * passes) gi puts the missing factors back at the last store
+    DevBuf g_u, gi_u;
+    int u_passes = 0;
     Fr n_inv;               // N^-1 (plain ifft post-multiply)
     Fr zinv;                // (7^N - 1)^-1 : 1 / Z on the coset (witness map)
 };

@@ -52,6 +52,16 @@ __device__ __forceinline__ void gst(Fr *p, const Fr &v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its own L2).  A column tile
+// touches 32 * C contiguous bytes per row, a row tile writes 32 * R: with C (R) = 1 or 2 a 128-byte line is shared by 4 (2)
+// neighbouring tiles.  Give those neighbours to consecutive blocks of ONE XCD, so the line is fetched / merged once in that
+// XCD's L2 instead of once per XCD (measured at 2^24, C = 1: FETCH_SIZE of the column pass 2.79 GB against 0.54 GB of data).
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned nblocks, unsigned group) {
+    if (group <= 1 || (nblocks % (8u * group)) != 0) return b;
+    const unsigned xcd = b & 7u, s = b >> 3;
+    return ((s / group) * 8u + xcd) * group + (s % group);
+}
+
 __device__ __forceinline__ int bitrev(int x, int bits) { return bits == 0 ? 0 : (int)(__brev((unsigned)x) >> (32 - bits)); }
 
 struct NttPassArgs {
@@ -213,40 +223,75 @@ __device__ __forceinline__ void lds_st_u(uint32_t *s, int stride, int e, const F
 // TL = log2 of the tile (11: twiddles of the sub-transform staged in LDS; 12: the tile fills the LDS, twiddles come from a
 // U-form table in global memory — used above 2^22, where it makes the transform two passes instead of three)
 template <int TL, bool GTW>
+__device__ __forceinline__ FrU tw_u(const uint32_t *s_tw, int tw_stride, int e, int log_m, const NttPassArgs &a) {
+    // twiddle w_M^e of the 2^log_m sub-transform, e < M/2: staged in LDS, or (GTW) read from the U-form table in global memory
+    if (GTW) {
+        const unsigned nmask = (1u << a.log_n) - 1u;
+        unsigned idx = (unsigned)e << (a.log_n - log_m);
+        if (a.inverse) idx = ((1u << a.log_n) - idx) & nmask;
+        const uint32_t *t = a.wu + (size_t)idx * 9;
+        FrU tw;
+#pragma unroll
+        for (int k = 0; k < 9; k++) tw.l[k] = t[k];
+        return tw;
+    }
+    return lds_ld_u(s_tw, tw_stride, e);
+}
+// decimation-in-frequency butterfly on (x, y): x <- x + y (< 2r), y <- (x - y) * tw (< 2r); last stage: tw = 1
+template <bool LAST>
+__device__ __forceinline__ void bfly_u(FrU &x, FrU &y, const FrU &tw) {
+    const FrU sum = fru_cond_sub<true>(fru_add(x, y));
+    const FrU dif = fru_sub_2r(x, y);
+    y = LAST ? fru_cond_sub<true>(dif) : fru_mul(dif, tw);
+    x = sum;
+}
+
+// TL = log2 of the tile (11: twiddles of the sub-transform staged in LDS; 12: the tile fills the LDS, twiddles come from a
+// U-form table in global memory — used above 2^22, where it makes the transform two passes instead of three).
+// Two butterfly stages per trip through the LDS (radix 4): a thread holds the four elements i, i + h/2, i + h, i + 3h/2 of a
+// stage-pair in registers, so the tile is read and written log_m / 2 times instead of log_m and the barriers halve; the
+// multiplications are the same four per group as two radix-2 stages.  An odd stage count ends with one radix-2 stage.
+template <int TL, bool GTW>
 __device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride, const NttPassArgs &a) {
     constexpr int TILE = 1 << TL;
     const int tid = threadIdx.x;
-    const unsigned nmask = (1u << a.log_n) - 1u;
-    for (int s = log_m - 1; s >= 0; s--) {
-        const int h = 1 << s;
-        for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
-            const int c = u >> (log_m - 1);
-            const int v = u & ((1 << (log_m - 1)) - 1);
-            const int j = v & (h - 1);
-            const int blk = v >> s;
+    int s = log_m - 1;
+    for (; s >= 1; s -= 2) {
+        const int h = 1 << s, q = h >> 1;
+        for (int u = tid; u < TILE / 4; u += NTT_THREADS_U) {
+            const int c = u >> (log_m - 2);
+            const int v = u & ((1 << (log_m - 2)) - 1);
+            const int j = v & (q - 1);
+            const int blk = v >> (s - 1);
             const int i0 = (c << log_m) + (blk << (s + 1)) + j;
-            const int i1 = i0 + h;
-            const FrU x = lds_ld_u(s_data, TILE, i0);
-            const FrU y = lds_ld_u(s_data, TILE, i1);
-            const FrU sum = fru_cond_sub<true>(fru_add(x, y));
-            FrU dif = fru_sub_2r(x, y);
-            if (s > 0) {
-                FrU tw;
-                if (GTW) {
-                    unsigned idx = (unsigned)(j << (log_m - 1 - s)) << (a.log_n - log_m);
-                    if (a.inverse) idx = ((1u << a.log_n) - idx) & nmask;
-                    const uint32_t *t = a.wu + (size_t)idx * 9;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) tw.l[k] = t[k];
-                } else {
-                    tw = lds_ld_u(s_tw, tw_stride, j << (log_m - 1 - s));
-                }
-                dif = fru_mul(dif, tw);
+            FrU x0 = lds_ld_u(s_data, TILE, i0), x1 = lds_ld_u(s_data, TILE, i0 + q);
+            FrU x2 = lds_ld_u(s_data, TILE, i0 + h), x3 = lds_ld_u(s_data, TILE, i0 + h + q);
+            // stage s (half h): (x0, x2) with w^j, (x1, x3) with w^(j + q)
+            bfly_u<false>(x0, x2, tw_u<TL, GTW>(s_tw, tw_stride, j << (log_m - 1 - s), log_m, a));
+            bfly_u<false>(x1, x3, tw_u<TL, GTW>(s_tw, tw_stride, (j + q) << (log_m - 1 - s), log_m, a));
+            // stage s - 1 (half q): (x0, x1) and (x2, x3), both with the same twiddle w'^j
+            if (s > 1) {
+                const FrU t1 = tw_u<TL, GTW>(s_tw, tw_stride, j << (log_m - s), log_m, a);
+                bfly_u<false>(x0, x1, t1);
+                bfly_u<false>(x2, x3, t1);
             } else {
-                dif = fru_cond_sub<true>(dif);       // the last stage's twiddle is w^0 = 1
+                bfly_u<true>(x0, x1, x0);
+                bfly_u<true>(x2, x3, x0);
             }
-            lds_st_u(s_data, TILE, i0, sum);
-            lds_st_u(s_data, TILE, i1, dif);
+            lds_st_u(s_data, TILE, i0, x0);
+            lds_st_u(s_data, TILE, i0 + q, x1);
+            lds_st_u(s_data, TILE, i0 + h, x2);
+            lds_st_u(s_data, TILE, i0 + h + q, x3);
+        }
+        __syncthreads();
+    }
+    if (s == 0) {                               // odd number of stages: the last one alone (twiddle 1)
+        for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
+            const int i0 = u << 1;
+            FrU x = lds_ld_u(s_data, TILE, i0), y = lds_ld_u(s_data, TILE, i0 + 1);
+            bfly_u<true>(x, y, x);
+            lds_st_u(s_data, TILE, i0, x);
+            lds_st_u(s_data, TILE, i0 + 1, y);
         }
         __syncthreads();
     }
@@ -262,18 +307,20 @@ __device__ __forceinline__ void stage_twiddles_u(uint32_t *s_tw, int tw_stride, 
     }
 }
 
-// element load: saturated -> U-form, times the optional per-index multiplier (coset fft), or the fused point-wise stage
-// (x * b - c) / Z: with X = x 2^256 etc. as stored,  X (*) B = xb 2^251,  C (*) 2^256 = c 2^251,  their difference (+2r) times
-// zc = 2^271 / Z gives (xb - c)/Z * 2^261, the U-form  ((*) = fru_mul = product * 2^-261; operands stay far below 70 r^2)
+// element load.  The stored (saturated Montgomery) limbs x 2^256 are used AS the U-form of x 2^-5: no conversion product.
+// The transform is linear, so every pass that loads this way leaves a factor 2^-5 behind, and the multiplier of the LAST
+// store carries 2^(5 * passes) (ntt_run).  The coset pre-multiply uses a table scaled by 2^10, which makes its one product a
+// full conversion (X 2^256 * g 2^10 2^256 * 2^-261 = x g 2^261).  Fused point-wise stage (x * b - c) / Z: X (*) B = xb 2^251,
+// C (*) 2^256 = c 2^251, their difference (+2r) times zc = 2^266 / Z is (xb - c)/Z * 2^256: like a plain load   ((*) = fru_mul).
 __device__ __forceinline__ FrU load_u(const NttPassArgs &a, const Fr *in, size_t gi) {
     const FrU x = fru_repack(gld(in + gi));
-    if (a.pre) return fru_mul(x, fru_mul(fru_repack(gld(a.pre + gi)), fru_c271()));
+    if (a.pre) return fru_mul(x, fru_repack(gld(a.pre + gi)));
     if (a.pw_b) {
         const FrU xb = fru_mul(x, fru_repack(gld(a.pw_b + gi)));
         const FrU c = fru_mul(fru_repack(gld(a.pw_c + gi)), fru_one_sat());
         return fru_mul(fru_sub_2r(xb, c), a.pw_zc);
     }
-    return fru_mul(x, fru_c266());
+    return x;                                 // canonical (< r), limbs < 2^29: a valid butterfly operand
 }
 
 template <int TL, bool GTW>
@@ -287,7 +334,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     const int C = 1 << log_c;
     const unsigned nmask = (1u << a.log_n) - 1u;
     const size_t n2 = (size_t)1 << a.log_n2;
-    const size_t col0 = (size_t)blockIdx.x * C;
+    const size_t col0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, C >= 4 ? 1u : 4u / (unsigned)C) * C;
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
     Fr *out = a.out + (size_t)blockIdx.y * a.batch_stride;
 
@@ -320,7 +367,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) 
     const int R = 1 << log_r;
     const size_t n1 = (size_t)1 << a.log_n1;
     const size_t n2 = (size_t)1 << a.log_n2;
-    const size_t row0 = (size_t)blockIdx.x * R;
+    const size_t row0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, R >= 4 ? 1u : 4u / (unsigned)R) * R;
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
 
     if (!GTW) stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
@@ -444,12 +491,42 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
     a.inverse = inverse ? 1 : 0;
     const Fr *pre = (!inverse && coset) ? t->g.as<Fr>() : nullptr;
     const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
-    const int post_const_on = (inverse && !coset) ? 1 : 0;
+    int post_const_on = (inverse && !coset) ? 1 : 0;
     a.post_const = t->n_inv;
+    if (uform) {
+        // passes that load without a conversion product (load_u): all of them, except the first when it carries the coset
+        // pre-multiply (a full conversion) or the fused point-wise stage (likewise)
+        const bool two_big = ctx->opt_ntt_mode != 3 && log_n > 2 * NTT_MAX_SUB_LOG && log_n <= 24;
+        const int passes = log_n <= NTT_MAX_SUB_LOG ? 1 : (two_big || log_n <= 2 * NTT_MAX_SUB_LOG) ? 2 : 3;
+        if (t->u_passes != passes || !t->g_u.p) {
+            DevBuf gu(n * sizeof(Fr)), giu(n * sizeof(Fr));
+            const Fr g = fr_from_u64_host(7), g_inv = fp_inv(g);
+            Fr back = fr_from_u64_host(1);
+            for (int i = 0; i < 5 * passes; i++) back = fp_add(back, back);
+            const unsigned grid = fr_powers_grid(n);
+            hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(256), 0, ctx->stream, gu.as<Fr>(), g, fr_from_u64_host(1024), n);
+            hipLaunchKernelGGL(fr_powers_kernel, dim3(grid), dim3(256), 0, ctx->stream, giu.as<Fr>(), g_inv, fp_mul(t->n_inv, back), n);
+            ZK_HIP(hipGetLastError());
+            ZK_HIP(hipStreamSynchronize(ctx->stream));      // first use only; cached once complete
+            t->g_u = std::move(gu);
+            t->gi_u = std::move(giu);
+            t->u_passes = passes;
+        }
+        // (the fused point-wise load is scaled to leave the same 2^-5 as a plain load, so one gi_u table serves both)
+        const int deficit = passes - (pre ? 1 : 0);
+        Fr back = fr_from_u64_host(1);
+        for (int i = 0; i < 5 * deficit; i++) back = fp_add(back, back);
+        if (pre) pre = t->g_u.as<Fr>();
+        if (post) post = t->gi_u.as<Fr>();
+        a.post_const = post_const_on ? fp_mul(t->n_inv, back) : back;
+        post_const_on = 1;                                  // the last store always multiplies (by 2^(5 deficit) at least)
+    }
     if (pw) {
         if (pre) throw HipError{hipErrorInvalidValue, "ntt: point-wise fusion needs a transform without a coset pre-multiply", __FILE__, __LINE__};
         a.pw_zinv = pw->zinv;
-        a.pw_zc = fru_repack(fp_mul(pw->zinv, fr_from_u64_host((uint64_t)1 << 15)));      // zinv * 2^15 * 2^256 = zinv 2^271 as an integer
+        // zinv * 2^10 * 2^256 = zinv 2^266 as an integer: (xb - c) 2^251 (*) zinv 2^266 = (xb - c)/Z * 2^256, i.e. the value with
+        // the same 2^-5 a plain load leaves (see load_u)
+        a.pw_zc = fru_repack(fp_mul(pw->zinv, fr_from_u64_host((uint64_t)1 << 10)));
     }
     // the pass that touches the input first carries the coset pre-multiply / the fused point-wise stage
     auto first = [&](NttPassArgs &p) {
