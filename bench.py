@@ -204,7 +204,7 @@ def main():
             sys.stderr.write("bench.py: process group has %d ranks, --gpus %d\n" % (dist.get_world_size(), args.gpus))
             sys.exit(2)
     from zksnark_finalproject_amd import Device
-    from zksnark_finalproject_amd.device import shard_plan, verify
+    from zksnark_finalproject_amd.device import shard_plan, verify, z_costs
 
     dev = Device(dev_index)
     sharded = world > 1 and args.parallel == "shard"
@@ -219,7 +219,7 @@ def main():
     setup_s = time.perf_counter() - t0
     plan, h_ranks = None, 1
     if sharded:
-        plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks)
+        plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks, z_costs(circ.r1cs, circ.z, circ.num_instance))
         z_lo, z_hi, h_lo, h_hi, blind = plan[rank]
         full = ph
         ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device; the whole key is dropped again

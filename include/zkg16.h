@@ -88,8 +88,10 @@ ZKG16_API int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t pk_handle, size_t z_lo, si
  * blinding: n_ranks flags (exactly one set).  The first *h_ranks_out ranks run the witness map and share h_query by index range;
  * every rank gets the share of the z ranges that makes all ranks finish together under a cost model in G1 mixed additions
  * (b_density = fraction of variables present in the B queries, <= 0 for the default 0.8; h_ranks = 0 lets the model choose,
- * h_ranks = n_ranks gives the equal split of zkg16_pk_load's shard_index / shard_count). */
-ZKG16_API int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks,
+ * h_ranks = n_ranks gives the equal split of zkg16_pk_load's shard_index / shard_count).  z_cost (nullable): m_total per-index
+ * costs of the z-side terms in G1 mixed additions — (0, 1 or window-count entries of the scalar) x (queries whose base is not
+ * at infinity, the G2 one counted 2.8x); with it the z ranges are cut by cumulative cost instead of by index count. */
+ZKG16_API int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost,
                      uint64_t *ranges /* n_ranks x 4 */, uint8_t *blinding /* n_ranks */, int *h_ranks_out);
 ZKG16_API void zkg16_pk_free(zkg16_ctx *ctx, uint64_t pk_handle);
 

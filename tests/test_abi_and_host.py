@@ -253,3 +253,25 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "refusing" in out.stderr
+
+
+def test_shard_plan_with_costs_balances_work_not_indices():
+    """With per-index costs (device.z_costs) the z ranges of the witness-map-free ranks carry equal cost although the witness of
+    the reference's MatrixCircuit is far from uniform (runs of 0 / 1 values, variables absent from the B queries)."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    from zksnark_finalproject_amd.device import shard_plan, z_costs
+    c = matrix_circuit(np.ones((8, 8), dtype=np.uint64), np.ones((8, 8), dtype=np.uint64))
+    zc = z_costs(c.r1cs, c.z, c.num_instance)
+    assert zc.shape[0] == c.num_vars and zc.min() >= 0 and zc[0] > 0       # the One variable: a scalar 1 in A
+    zero_vars = ~np.asarray(c.z).any(axis=1)
+    assert zero_vars.sum() >= 2 * 64 and not zc[zero_vars].any()              # matrix_c pre-allocation + the sums' seeds cost nothing
+    for ranks in (2, 4, 8):
+        plan, k = shard_plan(ranks, c.num_vars, c.domain - 1, 0.0, 0, zc)
+        pos = 0
+        for z_lo, z_hi, _, _, _ in plan:
+            assert z_lo == pos
+            pos = z_hi
+        assert pos == c.num_vars and sum(p[4] for p in plan) == 1
+        z_only = [float(zc[p[0]:p[1]].sum()) for p in plan[k:]]
+        if len(z_only) > 1:
+            assert max(z_only) <= 1.02 * min(z_only) + 2 * float(zc.max())

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from zksnark_finalproject_amd import Device
-from zksnark_finalproject_amd.device import shard_plan
+from zksnark_finalproject_amd.device import shard_plan, z_costs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 dev = Device(0)
@@ -19,11 +19,12 @@ full, vk = dev.setup_resident(rh, c.num_instance, trap, g1, g2)
 wh = dev.witness_load(c.z)
 r, s = bench.fr_mont(12345), bench.fr_mont(67890)
 reps = 3 if n >= 100 else 8
+costs = z_costs(c.r1cs, c.z, c.num_instance)
 print(desc, flush=True)
 single = None
 for G in Gs:
     for force in ([0] if G == 1 else [0, G]):
-        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force)
+        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force, None if force else costs)
         worst = 0.0
         per_rank = []
         seen = {}

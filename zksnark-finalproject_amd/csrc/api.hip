@@ -765,14 +765,23 @@ static int default_window_bits(size_t n) {
     while (((size_t)2 << lg) <= n) lg++;
     return lg - 3 < 4 ? 4 : lg - 3;
 }
-int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, uint64_t *ranges, uint8_t *blinding,
-                     int *h_ranks_out) {
+int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost, uint64_t *ranges,
+                     uint8_t *blinding, int *h_ranks_out) {
     if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
     if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
     constexpr double KAPPA = 2.8, OMEGA = 12.0;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
-    const double Z = (double)m_total * Wz * (2.0 + b_density * (1.0 + KAPPA)), H = (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
+    // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the
+    // queries in which its base is not the point at infinity, the G2 one counted KAPPA times) — the witness of a real circuit
+    // is not uniform (runs of 0 / 1 values, variables absent from B), so equal index ranges are not equal work
+    double Z = (double)m_total * Wz * (2.0 + b_density * (1.0 + KAPPA));
+    if (z_cost) {
+        Z = 0;
+        for (size_t i = 0; i < m_total; i++) Z += z_cost[i] > 0 ? (double)z_cost[i] : 0.0;
+        if (!(Z > 0)) Z = 1.0;
+    }
+    const double H = (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
     auto T_of = [&](int k) { const double a = (Z + H + k * WM) / G, b = WM + H / k; return a > b ? a : b; };
     int k = h_ranks;
     if (k == 0) {
@@ -789,12 +798,21 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
         cap_sum += cap[i];
     }
     if (!(cap_sum > 0)) { cap.assign(G, 1.0); cap_sum = G; }
-    double acc = 0;
-    size_t prev = 0;
+    double acc = 0, run = 0;
+    size_t prev = 0, pos = 0;
     bool blind_given = false;
     for (int i = 0; i < G; i++) {
         acc += cap[i];
-        size_t hi = i == G - 1 ? m_total : (size_t)((double)m_total * (acc / cap_sum) + 0.5);
+        size_t hi;
+        if (i == G - 1) {
+            hi = m_total;
+        } else if (!z_cost) {
+            hi = (size_t)((double)m_total * (acc / cap_sum) + 0.5);
+        } else {                                              // advance until this rank's share of the total cost is reached
+            const double target = Z * (acc / cap_sum);
+            while (pos < m_total && run < target) { run += z_cost[pos] > 0 ? (double)z_cost[pos] : 0.0; pos++; }
+            hi = pos;
+        }
         if (hi < prev) hi = prev;
         if (hi > m_total) hi = m_total;
         ranges[4 * i + 0] = prev;

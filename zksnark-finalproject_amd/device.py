@@ -224,14 +224,38 @@ class Device:
         self._check(self.lib.zkg16_set_option(self.ctx, name.encode(), int(value)))
 
 
-def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0):
+def z_costs(r1cs, z_mont, num_instance):
+    """Per-index cost of the z-side MSM terms in G1 mixed additions, for shard_plan: (entries of the scalar: 0 for a zero, 1 for a
+    one, one per window otherwise) x (queries whose base exists: A if the variable occurs in A or is an instance variable, L if it
+    is a witness, B1 + 2.8 x B2 if it occurs in B — ark-groth16 keeps the point at infinity for the rest)."""
+    z = _u64(z_mont).reshape(-1, 4)
+    m = z.shape[0]
+    n = m + 3
+    nwin = 254 // (17 if n >= (1 << 23) else 16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
+    one = np.array([0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f], dtype=np.uint64)      # 2^256 mod r
+    is_zero = ~z.any(axis=1)
+    is_one = (z == one).all(axis=1)
+    entries = np.where(is_zero, 0.0, np.where(is_one, 1.0, float(nwin)))
+    in_a = np.zeros(m, dtype=bool)
+    in_a[np.asarray(r1cs["a"][1], dtype=np.int64)] = True
+    in_a[:num_instance] = True
+    in_b = np.zeros(m, dtype=bool)
+    in_b[np.asarray(r1cs["b"][1], dtype=np.int64)] = True
+    mult = in_a.astype(np.float32) + (np.arange(m) >= num_instance) + in_b * 3.8
+    return (entries * mult).astype(np.float32)
+
+
+def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0, z_cost=None):
     """Rank roles of one proof over n_ranks GPUs (host-only zkg16_shard_plan) ->
-    (list of (z_lo, z_hi, h_lo, h_hi, blinding) per rank, number of ranks that run the witness map)."""
+    (list of (z_lo, z_hi, h_lo, h_hi, blinding) per rank, number of ranks that run the witness map).
+    z_cost: optional per-index costs (z_costs) so that the z ranges are cut by work, not by index count."""
     lib = _lib.load()
     ranges = np.zeros(4 * n_ranks, dtype=np.uint64)
     blind = np.zeros(n_ranks, dtype=np.uint8)
     k = C.c_int(0)
-    rc = lib.zkg16_shard_plan(n_ranks, m_total, n_h, float(b_density), h_ranks, ranges, blind, C.byref(k))
+    zc = None if z_cost is None else np.ascontiguousarray(z_cost, dtype=np.float32)
+    assert zc is None or zc.shape[0] == m_total
+    rc = lib.zkg16_shard_plan(n_ranks, m_total, n_h, float(b_density), h_ranks, _ptr(zc), ranges, blind, C.byref(k))
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     r = ranges.reshape(n_ranks, 4)
