@@ -22,6 +22,8 @@ reps = 3 if n >= 100 else 8
 costs = z_costs(c.r1cs, c.z, c.num_instance)
 print(desc, flush=True)
 single = None
+if 1 not in Gs:
+    Gs = [1] + Gs
 for G in Gs:
     for force in ([0] if G == 1 else [0, G]):
         plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force, None if force else costs)

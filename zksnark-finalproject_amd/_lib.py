@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzkg16.so")
+LIB_PATH = os.environ.get("ZKG16_LIB") or os.path.join(HERE, "libzkg16.so")      # ZKG16_LIB: an A/B build of the same ABI (tools/)
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")

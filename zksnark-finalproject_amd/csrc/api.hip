@@ -609,6 +609,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_wm_concurrent = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "acc_debug")) {          // timing probes of the accumulation kernels; results are WRONG while set
+        if (value < 0 || value > 3) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_acc_debug = (int)value;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "sort_mode")) {          // 0 (default): hand-written wave-ballot bucket scatter; 1: rocPRIM device radix sort
         if (value < 0 || value > 1) return ZKG16_ERR_BAD_ARG;
         ctx->opt_sort_mode = (int)value;
@@ -769,7 +774,10 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
                      uint8_t *blinding, int *h_ranks_out) {
     if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
     if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
-    constexpr double KAPPA = 2.8, OMEGA = 12.0;
+    // calibrated on one MI355X playing every rank in turn (tools/shard_timing.py, profiles/shard_timing_r2.txt): the z side costs
+    // ~1.2x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~12 additions
+    // per domain element (30.7 ms at 2^24)
+    constexpr double KAPPA = 2.8, OMEGA = 12.0, Z_OVERHEAD = 1.2, H_OVERHEAD = 1.1;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
     // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the
@@ -781,8 +789,24 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
         for (size_t i = 0; i < m_total; i++) Z += z_cost[i] > 0 ? (double)z_cost[i] : 0.0;
         if (!(Z > 0)) Z = 1.0;
     }
-    const double H = (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
-    auto T_of = [&](int k) { const double a = (Z + H + k * WM) / G, b = WM + H / k; return a > b ? a : b; };
+    Z *= Z_OVERHEAD;
+    const double H = H_OVERHEAD * (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
+    // fixed cost of taking part at all (latency chains that do not shrink with the share: the scatter passes and the four / one
+    // bucket reductions): ~3.5 ms for the z side, ~1.15 ms for the h side, in additions at 6.2 G/s.  With them a rank whose time
+    // is used up by the witness map and its h share takes no z work at all, and small circuits use fewer witness-map ranks.
+    constexpr double F_Z = 21.7e6, F_H = 7.0e6;
+    // time of the plan with k witness-map ranks: smallest T with  sum_i max(0, T - busy_i - F_Z) >= Z,  busy_i = WM + F_H + H/k (i < k)
+    auto busy_of = [&](int k, int i) { return i < k ? WM + (n_h ? F_H : 0.0) + H / k : 0.0; };
+    auto T_of = [&](int k) {
+        double lo = busy_of(k, 0), hi = lo + F_Z + Z + 1.0;
+        for (int it = 0; it < 80; it++) {
+            const double T = 0.5 * (lo + hi);
+            double c = 0;
+            for (int i = 0; i < G; i++) { const double x = T - busy_of(k, i) - F_Z; if (x > 0) c += x; }
+            if (c >= Z) hi = T; else lo = T;
+        }
+        return hi;
+    };
     int k = h_ranks;
     if (k == 0) {
         k = 1;
@@ -793,7 +817,7 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
     std::vector<double> cap(G);
     double cap_sum = 0;
     for (int i = 0; i < G; i++) {
-        cap[i] = i < k ? T - WM - H / k : T;
+        cap[i] = T - busy_of(k, i) - F_Z;
         if (cap[i] < 0) cap[i] = 0;
         cap_sum += cap[i];
     }
@@ -810,7 +834,7 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
             hi = (size_t)((double)m_total * (acc / cap_sum) + 0.5);
         } else {                                              // advance until this rank's share of the total cost is reached
             const double target = Z * (acc / cap_sum);
-            while (pos < m_total && run < target) { run += z_cost[pos] > 0 ? (double)z_cost[pos] : 0.0; pos++; }
+            while (pos < m_total && run < target) { run += Z_OVERHEAD * (z_cost[pos] > 0 ? (double)z_cost[pos] : 0.0); pos++; }
             hi = pos;
         }
         if (hi < prev) hi = prev;

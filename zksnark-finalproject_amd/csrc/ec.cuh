@@ -182,8 +182,13 @@ ZK_HD bool xyzz_madd_front(XYZZ<Fq2U> &acc, const Affine<Fq2U> &q_in, bool neg, 
         t.a = t.b = Fq2U::zero();
         return false;
     }
-    Fq2U U2 = f_mul(q.x, acc.zz);
-    Fq2U S2 = f_mul(q.y, acc.zzz);
+    // the first products inlined as well (ZK_G2_INLINE_FRONT of them): at one wave per SIMD a call's argument moves and waits are
+    // not hidden by a partner wave
+#ifndef ZK_G2_INLINE_FRONT
+#define ZK_G2_INLINE_FRONT 0      // measured at 128x128: 46.5 ms (0), 46.9 (2), 48.0 (5): the tail product alone is best
+#endif
+    Fq2U U2 = ZK_G2_INLINE_FRONT >= 1 ? fq2u_mul_inline(q.x, acc.zz) : f_mul(q.x, acc.zz);
+    Fq2U S2 = ZK_G2_INLINE_FRONT >= 2 ? fq2u_mul_inline(q.y, acc.zzz) : f_mul(q.y, acc.zzz);
     Fq2U Pp = f_sub2(U2, acc.x);
     Fq2U R = f_sub2(S2, acc.y);
     if (f_is_zero_mod(Pp)) {
@@ -193,9 +198,9 @@ ZK_HD bool xyzz_madd_front(XYZZ<Fq2U> &acc, const Affine<Fq2U> &q_in, bool neg, 
         return false;
     }
     Fq2U PP = f_sqr(Pp);
-    Fq2U PPP = f_mul(Pp, PP);
-    acc.zz = f_mul(acc.zz, PP);
-    Fq2U Q = f_mul(acc.x, PP);
+    Fq2U PPP = ZK_G2_INLINE_FRONT >= 3 ? fq2u_mul_inline(Pp, PP) : f_mul(Pp, PP);
+    acc.zz = ZK_G2_INLINE_FRONT >= 4 ? fq2u_mul_inline(acc.zz, PP) : f_mul(acc.zz, PP);
+    Fq2U Q = ZK_G2_INLINE_FRONT >= 5 ? fq2u_mul_inline(acc.x, PP) : f_mul(acc.x, PP);
     Fq2U X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
     acc.y = f_sub(f_mul(R, f_sub2(Q, X3)), f_mul(acc.y, PPP));
     acc.x = X3;

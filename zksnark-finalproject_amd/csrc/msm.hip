@@ -171,6 +171,7 @@ struct AccArgs {
     const uint32_t *total_ptr;  // number of sorted entries (= offsets[total_buckets]); read on the device, no host sync
     size_t total_buckets;
     const uint32_t *seg_len_ptr; // entries per lane, computed on the device from the exact entry count (msm_seg_params_kernel)
+    uint32_t debug;              // timing probes only (option "acc_debug"; results are WRONG): bit 0 = no bucket stores, bit 1 = always gather base 0
 };
 
 // G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
@@ -203,9 +204,9 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
                 // next is its TAIL partial (a bucket doing both is recorded as head only); everything else is complete.
                 if (cur == g_first && head_open) {
                     head_b = (int32_t)cur;
-                    stv(a.seg_head + t, acc);
+                    if (!(a.debug & 1u)) stv(a.seg_head + t, acc);
                 } else if (!acc.is_inf()) {
-                    stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+                    if (!(a.debug & 1u)) stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
                 }
                 acc = XYZZ<F>::inf();
                 cur = gb;
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
             // result with the old value, and those wait for it at once.  The last iteration re-reads its own entry / base.
             en = en1;
             en1 = a.entries[p + 2 < end ? p + 2 : end - 1];
-            bq = ldv(a.bases + (en.x >> 1));
+            bq = ldv(a.bases + ((a.debug & 2u) ? 0u : (en.x >> 1)));
             asm volatile("" ::: "memory");            // the loads above stay above the inlined product
             xyzz_madd_finish(acc, tail, normal);
         }
@@ -747,6 +748,7 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     a.total_ptr = ws.offsets.as<uint32_t>() + tb;
     a.total_buckets = tb;
     a.seg_len_ptr = ws.seg_params.as<uint32_t>() + (FieldTraits<F>::g2 ? 1 : 0);
+    a.debug = (uint32_t)ctx->opt_acc_debug;
     const unsigned grid = (unsigned)((nseg + 63) / 64);
     {
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
