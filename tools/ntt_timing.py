@@ -1,14 +1,24 @@
-"""Standalone NTT timings by mode (development probe): python tools/ntt_timing.py [log sizes...]
-   mode 0 = saturated limbs, 1 = unsaturated (two 4096-point passes at 2^23-2^24), 3 = unsaturated with three passes there"""
+"""Stand-alone NTT / witness-map timings under library options (development probe):
+   python tools/ntt_timing.py [opt=v0,v1 ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench
 from zksnark_finalproject_amd import Device
 dev = Device(0)
-for log_n in [int(x) for x in (sys.argv[1:] or ["16", "19", "20", "22", "23", "24"])]:
-    for mode in (0, 3, 1):
-        dev.set_option("ntt_mode", mode)
-        dev.bench_ntt(log_n, 1, 1, 2)
-        ms = dev.bench_ntt(log_n, 1, 1, 10)
-        n = 1 << log_n
-        print("ntt 2^%d coset-inverse ntt_mode=%d: %.3f ms  (%.1f GB/s of the 64 B/element algorithmic traffic)" % (log_n, mode, ms, 64.0 * n / ms / 1e6), flush=True)
+sweeps = [(a.split("=")[0], [int(x) for x in a.split("=")[1].split(",")]) for a in sys.argv[1:]] or [("ntt_xcd", [1])]
+circs = {}
+for n in (32, 128):
+    c, _, _ = bench.synthesize("matrix", n)
+    circs[n] = (dev.r1cs_load(c.r1cs, c.num_vars), dev.witness_load(c.z))
+for opt, vals in sweeps:
+    for v in vals:
+        dev.set_option(opt, v)
+        line = ["%s=%d:" % (opt, v)]
+        for log_n in (16, 19, 20, 22, 24):
+            dev.bench_ntt(log_n, 1, 1, 2)
+            line.append("2^%d %.3f ms" % (log_n, dev.bench_ntt(log_n, 1, 1, 8)))
+        for n, (rh, wh) in circs.items():
+            line.append("witness map n=%d %.3f ms" % (n, dev.bench_witness_map(rh, wh, 4)))
+        print("  ".join(line), flush=True)
+    dev.set_option(opt, 0)

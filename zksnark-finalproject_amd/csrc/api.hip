@@ -609,6 +609,16 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_wm_concurrent = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "ntt_radix")) {          // 2 (default; also 0): one butterfly stage per LDS trip; 4: two (radix 4)
+        if (value != 0 && value != 2 && value != 4) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_ntt_radix = value == 4 ? 4 : 2;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "ntt_xcd")) {            // 1 (default): XCD-aware tile order in the NTT passes; 2 = off (0 restores the default)
+        if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_ntt_xcd = value == 2 ? 0 : 1;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "acc_debug")) {          // timing probes of the accumulation kernels; results are WRONG while set
         if (value < 0 || value > 3) return ZKG16_ERR_BAD_ARG;
         ctx->opt_acc_debug = (int)value;

@@ -84,6 +84,7 @@ struct NttPassArgs {
     int tw_shift;                // inter-pass twiddle index is (i2*k1) << tw_shift   (w_M = w_N^(2^tw_shift))
     size_t batch_stride;         // elements between consecutive batches in `in` (and in `out` for in-place passes)
     int out_stride_log;          // rows pass: final index = batch + (k << out_stride_log)
+    int xcd_order;               // 1: neighbouring tiles go to consecutive blocks of one XCD (xcd_tile); option "ntt_xcd"
 };
 
 // DIF over `ncols` independent sub-transforms of size 2^log_m laid out back to back in the LDS tile.
@@ -248,14 +249,34 @@ __device__ __forceinline__ void bfly_u(FrU &x, FrU &y, const FrU &tw) {
 
 // TL = log2 of the tile (11: twiddles of the sub-transform staged in LDS; 12: the tile fills the LDS, twiddles come from a
 // U-form table in global memory — used above 2^22, where it makes the transform two passes instead of three).
-// Two butterfly stages per trip through the LDS (radix 4): a thread holds the four elements i, i + h/2, i + h, i + 3h/2 of a
-// stage-pair in registers, so the tile is read and written log_m / 2 times instead of log_m and the barriers halve; the
-// multiplications are the same four per group as two radix-2 stages.  An odd stage count ends with one radix-2 stage.
-template <int TL, bool GTW>
+// R4 (option "ntt_radix" = 4): two butterfly stages per trip through the LDS — a thread holds the four elements i, i + h/2,
+// i + h, i + 3h/2 of a stage pair in registers, so the tile is read and written log_m / 2 times and the barriers halve; the
+// multiplications are the same four per group.  Measured: equal to one stage per trip up to 2^22, SLOWER at 2^24 (3.44 vs
+// 3.07 ms per transform: the kernel is multiplier-bound, and the four live elements cost registers), so it is not the default.
+template <int TL, bool GTW, bool R4>
 __device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride, const NttPassArgs &a) {
     constexpr int TILE = 1 << TL;
     const int tid = threadIdx.x;
     int s = log_m - 1;
+    if (!R4) {                                  // one stage per trip (default)
+        for (; s >= 0; s--) {
+            const int h = 1 << s;
+            for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
+                const int c = u >> (log_m - 1);
+                const int v = u & ((1 << (log_m - 1)) - 1);
+                const int j = v & (h - 1);
+                const int blk = v >> s;
+                const int i0 = (c << log_m) + (blk << (s + 1)) + j;
+                FrU x = lds_ld_u(s_data, TILE, i0), y = lds_ld_u(s_data, TILE, i0 + h);
+                if (s > 0) bfly_u<false>(x, y, tw_u<TL, GTW>(s_tw, tw_stride, j << (log_m - 1 - s), log_m, a));
+                else bfly_u<true>(x, y, x);
+                lds_st_u(s_data, TILE, i0, x);
+                lds_st_u(s_data, TILE, i0 + h, y);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (; s >= 1; s -= 2) {
         const int h = 1 << s, q = h >> 1;
         for (int u = tid; u < TILE / 4; u += NTT_THREADS_U) {
@@ -323,7 +344,7 @@ __device__ __forceinline__ FrU load_u(const NttPassArgs &a, const Fr *in, size_t
     return x;                                 // canonical (< r), limbs < 2^29: a valid butterfly operand
 }
 
-template <int TL, bool GTW>
+template <int TL, bool GTW, bool R4>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) {
     constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -334,7 +355,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     const int C = 1 << log_c;
     const unsigned nmask = (1u << a.log_n) - 1u;
     const size_t n2 = (size_t)1 << a.log_n2;
-    const size_t col0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, C >= 4 ? 1u : 4u / (unsigned)C) * C;
+    const size_t col0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, (C >= 4 || !a.xcd_order) ? 1u : 4u / (unsigned)C) * C;
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
     Fr *out = a.out + (size_t)blockIdx.y * a.batch_stride;
 
@@ -345,7 +366,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
         lds_st_u(s_data, TILE, (c << a.log_n1) + i1, load_u(a, in, gi));
     }
     __syncthreads();
-    lds_dif_u<TL, GTW>(s_data, s_tw, a.log_n1, tw_stride, a);
+    lds_dif_u<TL, GTW, R4>(s_data, s_tw, a.log_n1, tw_stride, a);
     for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int c = t & (C - 1), k1 = t >> log_c;
         const FrU v = lds_ld_u(s_data, TILE, (c << a.log_n1) + bitrev(k1, a.log_n1));
@@ -356,7 +377,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     }
 }
 
-template <int TL, bool GTW>
+template <int TL, bool GTW, bool R4>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) {
     constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -367,7 +388,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) 
     const int R = 1 << log_r;
     const size_t n1 = (size_t)1 << a.log_n1;
     const size_t n2 = (size_t)1 << a.log_n2;
-    const size_t row0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, R >= 4 ? 1u : 4u / (unsigned)R) * R;
+    const size_t row0 = (size_t)xcd_tile(blockIdx.x, gridDim.x, (R >= 4 || !a.xcd_order) ? 1u : 4u / (unsigned)R) * R;
     const Fr *in = a.in + (size_t)blockIdx.y * a.batch_stride;
 
     if (!GTW) stage_twiddles_u(s_tw, tw_stride, a.w, a.log_n, a.log_n2, a.inverse);
@@ -380,7 +401,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) 
         lds_st_u(s_data, TILE, t, v);
     }
     __syncthreads();
-    lds_dif_u<TL, GTW>(s_data, s_tw, a.log_n2, tw_stride, a);
+    lds_dif_u<TL, GTW, R4>(s_data, s_tw, a.log_n2, tw_stride, a);
     const FrU post_c = a.post_const_on ? fru_repack(a.post_const) : fru_one_sat();
     for (int t = threadIdx.x; t < TILE; t += NTT_THREADS_U) {
         const int r = t & (R - 1), k2 = t >> log_r;
@@ -472,14 +493,17 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
     bool &lds_attr_set = ctx->lds_attr_ntt;          // per ctx (= per device)
     if (!lds_attr_set) {   // 64-72 KiB tile + up to 36 KiB of twiddles, or a 144 KiB tile: above the 64 KiB default dynamic-LDS cap
         for (const void *f : {reinterpret_cast<const void *>(ntt_pass_cols), reinterpret_cast<const void *>(ntt_pass_rows),
-                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false>),
-                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true>)})
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, true>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, true>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, false>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, false>)})
             ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     const bool uform = ctx->opt_ntt_mode != 0;          // 1 (default): unsaturated butterflies; 0: saturated (the first version)
-    auto *k_cols = uform ? ntt_pass_cols_u<11, false> : ntt_pass_cols;
-    auto *k_rows = uform ? ntt_pass_rows_u<11, false> : ntt_pass_rows;
+    const bool r4 = ctx->opt_ntt_radix != 2;
+    auto *k_cols = uform ? (r4 ? ntt_pass_cols_u<11, false, true> : ntt_pass_cols_u<11, false, false>) : ntt_pass_cols;
+    auto *k_rows = uform ? (r4 ? ntt_pass_rows_u<11, false, true> : ntt_pass_rows_u<11, false, false>) : ntt_pass_rows;
     const unsigned nthreads = uform ? NTT_THREADS_U : NTT_THREADS;
     if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
@@ -489,6 +513,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
     a.w = t->w.as<Fr>();
     a.log_n = log_n;
     a.inverse = inverse ? 1 : 0;
+    a.xcd_order = ctx->opt_ntt_xcd;
     const Fr *pre = (!inverse && coset) ? t->g.as<Fr>() : nullptr;
     const Fr *post = (inverse && coset) ? t->gi.as<Fr>() : nullptr;
     int post_const_on = (inverse && !coset) ? 1 : 0;
@@ -556,7 +581,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p1.batch_stride = 0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (12 - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            hipLaunchKernelGGL((ntt_pass_cols_u<12, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            if (r4) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            else hipLaunchKernelGGL((ntt_pass_cols_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
         }
         {
             NttPassArgs p2 = a;
@@ -565,7 +591,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p2.post_const_on = post_const_on;
             const unsigned grid = (unsigned)((size_t)1 << a.log_n1);
             ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-            hipLaunchKernelGGL((ntt_pass_rows_u<12, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            if (r4) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            else hipLaunchKernelGGL((ntt_pass_rows_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
         }
     } else if (log_n <= NTT_MAX_SUB_LOG) {
         a.log_n1 = 0;
