@@ -8,12 +8,12 @@ from zksnark_finalproject_amd import Device, handlers
 from zksnark_finalproject_amd.circuits import fibonacci_circuit, matrix_circuit
 dev = Device(0)
 for name, circ in (("fibonacci 186 rounds", fibonacci_circuit(0, 1, 186)), ("fibonacci 1000 rounds", fibonacci_circuit(0, 1, 1000)),
-                   ("matrix 4x4", matrix_circuit(np.ones((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64)))):
-    shp = dict(num_vars=circ.num_vars, num_instance=circ.num_instance, domain=circ.domain)
-    pk = bench.make_key(dev, circ.r1cs, shp, seed=3)
-    ph, rh, wh = dev.pk_load(pk, circ.num_instance), dev.r1cs_load(circ.r1cs, circ.num_vars), dev.witness_load(circ.z)
-    rng = np.random.default_rng(5)
-    r, s = bench.rand_fr_mont(rng), bench.rand_fr_mont(rng)
+                   ("matrix 4x4", matrix_circuit(np.ones((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64))),
+                   ("prime circuit", __import__("zksnark_finalproject_amd.circuits", fromlist=["prime_circuit"]).prime_circuit(5, 32))):
+    trap, g1, g2 = bench.draw_key_inputs(3)
+    rh, wh = dev.r1cs_load(circ.r1cs, circ.num_vars), dev.witness_load(circ.z)
+    ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
+    r, s = bench.fr_mont(12345), bench.fr_mont(67890)
     for _ in range(3):
         dev.prove_resident(ph, rh, wh, r, s)
     t0 = time.perf_counter()

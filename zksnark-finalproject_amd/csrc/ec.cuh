@@ -134,6 +134,17 @@ ZK_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
 // front() does everything else, including all exceptional cases (then it returns false and finish() changes nothing).
 template <class F> struct MaddTail { F a, b, c, d; };
 
+// ZK_G1_INLINE_FRONT: the nine products of the G1 front part inlined too (no call at all on the main path; ~45 KB of loop body)
+#ifndef ZK_G1_INLINE_FRONT
+#define ZK_G1_INLINE_FRONT 0
+#endif
+#if ZK_G1_INLINE_FRONT
+#define ZK_G1M(a, b) fqu_mul_impl<false>(a, b)
+#define ZK_G1S(a) fqu_mul_impl<true>(a, a)
+#else
+#define ZK_G1M(a, b) f_mul(a, b)
+#define ZK_G1S(a) f_sqr(a)
+#endif
 ZK_HD bool xyzz_madd_front(XYZZ<FqU> &acc, const Affine<FqU> &q_in, bool neg, MaddTail<FqU> &t) {
     if (q_in.is_inf()) { t.a = t.b = t.c = t.d = FqU::zero(); return false; }
     Affine<FqU> q = q_in;
@@ -143,8 +154,8 @@ ZK_HD bool xyzz_madd_front(XYZZ<FqU> &acc, const Affine<FqU> &q_in, bool neg, Ma
         t.a = t.b = t.c = t.d = FqU::zero();
         return false;
     }
-    FqU U2 = f_mul(q.x, acc.zz);
-    FqU S2 = f_mul(q.y, acc.zzz);
+    FqU U2 = ZK_G1M(q.x, acc.zz);
+    FqU S2 = ZK_G1M(q.y, acc.zzz);
     FqU Pp = f_sub2(U2, acc.x);
     FqU R = f_sub2(S2, acc.y);
     if (f_is_zero_mod(Pp)) {
@@ -155,12 +166,12 @@ ZK_HD bool xyzz_madd_front(XYZZ<FqU> &acc, const Affine<FqU> &q_in, bool neg, Ma
     }
     // order chosen for register pressure: at most six field elements are live across any call (values that survive a call
     // must sit in the callee-saved half of the register file)
-    FqU PP = f_sqr(Pp);
-    FqU PPP = f_mul(Pp, PP);
-    acc.zz = f_mul(acc.zz, PP);
-    acc.zzz = f_mul(acc.zzz, PPP);
-    FqU Q = f_mul(acc.x, PP);
-    FqU X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    FqU PP = ZK_G1S(Pp);
+    FqU PPP = ZK_G1M(Pp, PP);
+    acc.zz = ZK_G1M(acc.zz, PP);
+    acc.zzz = ZK_G1M(acc.zzz, PPP);
+    FqU Q = ZK_G1M(acc.x, PP);
+    FqU X3 = f_sub(ZK_G1S(R), f_add(PPP, f_dbl(Q)));
     t.a = R;
     t.b = f_sub2(Q, X3);
     t.c = fqu_sub<64>(FqU::zero(), acc.y);
