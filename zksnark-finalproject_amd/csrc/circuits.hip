@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -770,21 +771,56 @@ int zkg16_circuit_is_satisfied(const zkg16_circuit *c) {
 int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3], uint64_t *z) {
     if (!c || c->segs.empty() || !row_ptr || !col || !coeff || !z) return ZKG16_ERR_BAD_ARG;
     const size_t ni = c->head().instance.size();
+    // (matrix, segment) pieces with their row / term offsets; the copies are plain streaming work (3.7 GB at 128x128), cut into
+    // tasks of ~2^18 terms and spread over the host threads (ZKG16_SYNTH_THREADS=0: this thread only)
+    struct Task { int m; const Circuit::Rows *r; size_t row0, k0, r_lo, r_hi; };
+    std::vector<Task> tasks;
+    size_t witness_terms = 0;
     for (int m = 0; m < 3; m++) {
         size_t row = 0, k = 0;
         row_ptr[m][0] = 0;
         for (const auto &sg : c->segs) {
             const Circuit::Rows &r = sg->rows[m];
-            for (size_t i = 1; i < r.ptr.size(); i++) row_ptr[m][row + i] = k + r.ptr[i];
-            // instance columns first, then witnesses (ids are already ordered that way within a row)
-            for (size_t j = 0; j < r.t.size(); j++) {
-                const Term &t = r.t[j];
-                col[m][k + j] = (t.v & WIT) ? (uint32_t)(ni + (t.v & ~WIT)) : t.v;
-                memcpy(coeff[m] + 4 * (k + j), t.c.l, 32);
+            const size_t nrows = r.size();
+            size_t lo = 0;
+            while (lo < nrows) {
+                size_t hi = lo;
+                while (hi < nrows && r.ptr[hi] - r.ptr[lo] < ((size_t)1 << 18)) hi++;
+                if (hi == lo) hi = lo + 1;
+                tasks.push_back(Task{m, &r, row, k, lo, hi});
+                lo = hi;
             }
-            row += r.size();
+            row += nrows;
             k += r.t.size();
         }
+        witness_terms += k;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t id = next.fetch_add(1);
+            if (id >= tasks.size()) break;
+            const Task &t = tasks[id];
+            const Circuit::Rows &r = *t.r;
+            for (size_t i = t.r_lo; i < t.r_hi; i++) row_ptr[t.m][t.row0 + i + 1] = t.k0 + r.ptr[i + 1];
+            // instance columns first, then witnesses (ids are already ordered that way within a row)
+            for (size_t j = r.ptr[t.r_lo]; j < r.ptr[t.r_hi]; j++) {
+                const Term &x = r.t[j];
+                col[t.m][t.k0 + j] = (x.v & WIT) ? (uint32_t)(ni + (x.v & ~WIT)) : x.v;
+                memcpy(coeff[t.m] + 4 * (t.k0 + j), x.c.l, 32);
+            }
+        }
+    };
+    const char *env = getenv("ZKG16_SYNTH_THREADS");
+    unsigned nthreads = (env && env[0] == '0') ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (witness_terms < ((size_t)1 << 20)) nthreads = 1;
+    try {
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < nthreads; i++) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    } catch (const std::exception &) {
+        return ZKG16_ERR_OOM;
     }
     memcpy(z, c->head().instance.data(), ni * 32);
     for (const auto &sg : c->segs)
