@@ -260,10 +260,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         extra[0] = pk.blinding ? r : Fr::zero();              // the r/s/-rs terms are added by one shard only
         extra[1] = pk.blinding ? s : Fr::zero();
         extra[2] = pk.blinding ? fp_neg(fp_mul(r, s)) : Fr::zero();
-        ctx->ws_z.stage.ensure(3 * sizeof(Fr));
-        Fr *stage = ctx->ws_z.stage.as<Fr>();
-        ZK_HIP(hipMemcpyAsync(stage, extra, 3 * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));   // pinned; reused only after this proof
-        ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, stage, 3, true, nullptr};
+        // the digit kernel reads the three extra scalars straight from this pinned (device-visible) host buffer: no host-to-device
+        // copy is queued; the buffer is rewritten only by the next proof, which starts after this one has been collected
+        ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, extra, 3, true, nullptr};
         msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z);
         if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
             zsrc.mask = pk.b_mask.as<uint8_t>();
@@ -785,9 +784,9 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
     if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
     if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
     // calibrated on one MI355X playing every rank in turn (tools/shard_timing.py, profiles/shard_timing_r2.txt): the z side costs
-    // ~1.2x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~12 additions
-    // per domain element (30.7 ms at 2^24)
-    constexpr double KAPPA = 2.8, OMEGA = 12.0, Z_OVERHEAD = 1.2, H_OVERHEAD = 1.1;
+    // ~1.2x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~10.5 additions
+    // per domain element (27.6 ms at 2^24)
+    constexpr double KAPPA = 2.8, OMEGA = 10.5, Z_OVERHEAD = 1.2, H_OVERHEAD = 1.1;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
     // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the

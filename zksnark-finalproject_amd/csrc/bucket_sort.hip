@@ -38,7 +38,7 @@ struct SortPass {
     uint2 *out;
     uint32_t *counts;            // [window][digit][block]  (after `scan`: exclusive prefix over the blocks)
     uint32_t *dig_total;         // [window][digit]
-    uint32_t *win_total;         // [window]: elements of this pass's output per window (zeroed before `scan`)
+    uint32_t *win_total;         // [window]: elements of this pass's output per window (sort_window_total_kernel)
     const uint32_t *in_count;    // pass 1: elements per window in `in` (= pass 0's win_total); pass 0: null (n each)
     size_t n;                    // scalars per window
     uint32_t nblk;               // workgroups per window = ceil(n / SORT_BCH)
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64 * SORT_WAVES) sort_count_kernel(SortPass a)
     }
 }
 
-// one wave per (window, digit): counts[w][d][0 .. nblk) -> exclusive prefix; total -> dig_total, += win_total[w]
+// one wave per (window, digit): counts[w][d][0 .. nblk) -> exclusive prefix; total -> dig_total
 __global__ void __launch_bounds__(64) sort_scan_kernel(SortPass a) {
     const uint32_t lane = threadIdx.x, d = blockIdx.x, w = blockIdx.y;
     const uint32_t ndig = 1u << a.bits;
@@ -146,10 +146,17 @@ __global__ void __launch_bounds__(64) sort_scan_kernel(SortPass a) {
         if (i < a.nblk) row[i] = carry + inc - v;
         carry += __shfl(inc, 63, 64);
     }
-    if (lane == 0) {
-        a.dig_total[w * ndig + d] = carry;
-        if (carry) atomicAdd(a.win_total + w, carry);          // integer sum: the result does not depend on the order
-    }
+    if (lane == 0) a.dig_total[w * ndig + d] = carry;
+}
+
+// one wave per window: win_total[w] = sum of the window's digit totals (what the passes use as window sizes / bases)
+__global__ void __launch_bounds__(64) sort_window_total_kernel(SortPass a) {
+    const uint32_t lane = threadIdx.x, w = blockIdx.x;
+    const uint32_t ndig = 1u << a.bits;
+    uint32_t s = 0;
+    for (uint32_t d = lane; d < ndig; d += 64) s += a.dig_total[w * ndig + d];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) a.win_total[w] = s;
 }
 
 // exclusive scan of one value per thread over the 256 threads of the block (scratch: SORT_WAVES words of LDS); returns the
@@ -258,7 +265,6 @@ const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t
     uint32_t *counts = ws.sort_temp.as<uint32_t>();
     uint32_t *dig_total = counts + counts_words;
     uint32_t *win0 = dig_total + (size_t)nwin * ndig_max, *win1 = win0 + nwin;
-    ZK_HIP(hipMemsetAsync(win0, 0, 2 * (size_t)nwin * sizeof(uint32_t), ctx->stream));
     SortPass a{};
     a.codes = codes;
     a.counts = counts;
@@ -275,6 +281,7 @@ const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t
     a.win_total = win0;
     hipLaunchKernelGGL(sort_count_kernel<0>, grid, block, sort_lds_bytes(bits0, false), ctx->stream, a);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(1u << bits0, (unsigned)nwin), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(sort_window_total_kernel, dim3((unsigned)nwin), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(sort_scatter_kernel<0>, grid, block, sort_lds_bytes(bits0, true), ctx->stream, a);
     // pass 1: high bits; intermediate list -> entries (global bucket ids, compact over the windows)
     a.pass = 1; a.shift = bits0; a.bits = bits1;
@@ -284,6 +291,7 @@ const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t
     a.win_total = win1;
     hipLaunchKernelGGL(sort_count_kernel<1>, grid, block, sort_lds_bytes(bits1, false), ctx->stream, a);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(1u << bits1, (unsigned)nwin), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(sort_window_total_kernel, dim3((unsigned)nwin), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(sort_scatter_kernel<1>, grid, block, sort_lds_bytes(bits1, true), ctx->stream, a);
     ZK_HIP(hipGetLastError());
     return win1;

@@ -808,7 +808,14 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     slot.red_a.ensure(tot * psz);
     slot.red_b.ensure(tot * psz);
     slot.red_c.ensure(tot * psz);
-    slot.wsums_dev.ensure(nout * sizeof(XYZZ<FS>));
+    // the window sums are written straight into pinned host memory by the conversion kernel (device-visible, coherent): no
+    // device-to-host copy is queued, so no runtime blit kernel appears inside a proof
+    if (slot.host_bytes < nout * sizeof(XYZZ<FS>)) {
+        if (slot.wsums_host) (void)hipHostFree(slot.wsums_host);
+        slot.host_bytes = 128 * sizeof(XYZZ<FS>) > nout * sizeof(XYZZ<FS>) ? 128 * sizeof(XYZZ<FS>) : nout * sizeof(XYZZ<FS>);
+        ZK_HIP(hipHostMalloc(&slot.wsums_host, slot.host_bytes, hipHostMallocDefault));
+    }
+    XYZZ<FS> *wsums_out = reinterpret_cast<XYZZ<FS> *>(slot.wsums_host);
     XYZZ<F> *pa = slot.red_a.as<XYZZ<F>>(), *pb = slot.red_b.as<XYZZ<F>>(), *pc = slot.red_c.as<XYZZ<F>>();
     const unsigned rgrid = (unsigned)((tot + 63) / 64);
     // weighted reduction of `src_buckets` ([nwin][nb_] entries) with chunks of k_: result of window w at res[w * (nb_ / k_)]
@@ -833,7 +840,7 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
         ScopedKernelTimer kt(ctx, rname, (double)tb, aux);
         if (!slot.two_level_k) {
             weighted(a.buckets, plan.nb, kk, pa, pb, pc);
-            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc, nchunks, slot.wsums_dev.as<XYZZ<FS>>(), plan.nwin);
+            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc, nchunks, wsums_out, plan.nwin);
         } else {
             // S -> pa, M -> pb; the second level works in pc, split in three
             hipLaunchKernelGGL(msm_chunk_local_kernel<F>, dim3(rgrid), dim3(64), 0, aux, a.buckets, pa, pb, plan.nb, kk, plan.nwin);
@@ -845,17 +852,11 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
                 hipLaunchKernelGGL(msm_sum_step_kernel<F>, dim3((unsigned)((half * plan.nwin + 63) / 64)), dim3(64), 0, aux, pb, nchunks, half, live, plan.nwin);
                 live = half;
             }
-            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc + 2 * n2, nchunks / kk2, slot.wsums_dev.as<XYZZ<FS>>(), plan.nwin);
-            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pb, nchunks, slot.wsums_dev.as<XYZZ<FS>>() + plan.nwin, plan.nwin);
+            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc + 2 * n2, nchunks / kk2, wsums_out, plan.nwin);
+            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pb, nchunks, wsums_out + plan.nwin, plan.nwin);
         }
     }
     ZK_HIP(hipGetLastError());
-    if (slot.host_bytes < nout * sizeof(XYZZ<FS>)) {
-        if (slot.wsums_host) (void)hipHostFree(slot.wsums_host);
-        slot.host_bytes = 128 * sizeof(XYZZ<FS>) > nout * sizeof(XYZZ<FS>) ? 128 * sizeof(XYZZ<FS>) : nout * sizeof(XYZZ<FS>);
-        ZK_HIP(hipHostMalloc(&slot.wsums_host, slot.host_bytes, hipHostMallocDefault));
-    }
-    ZK_HIP(hipMemcpyAsync(slot.wsums_host, slot.wsums_dev.p, nout * sizeof(XYZZ<FS>), hipMemcpyDeviceToHost, aux));
     ZK_HIP(hipEventRecord(slot.red_done, aux));
     slot.active = true;
 }
