@@ -784,9 +784,9 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
     if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
     if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
     // calibrated on one MI355X playing every rank in turn (tools/shard_timing.py, profiles/shard_timing_r2.txt): the z side costs
-    // ~1.2x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~10.5 additions
+    // ~1.26x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~10.5 additions
     // per domain element (27.6 ms at 2^24)
-    constexpr double KAPPA = 2.8, OMEGA = 10.5, Z_OVERHEAD = 1.2, H_OVERHEAD = 1.1;
+    constexpr double KAPPA = 2.8, OMEGA = 10.5, Z_OVERHEAD = 1.26, H_OVERHEAD = 1.1;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
     // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the
