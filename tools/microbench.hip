@@ -167,6 +167,77 @@ __global__ void __launch_bounds__(64) k_madd(uint32_t *out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = ((uint32_t *)&acc)[0] ^ seed;
 }
 
+// ---- batched-affine bucket addition, the alternative to the XYZZ mixed addition: a lane adds B
+// independent pairs P_i + Q_i in AFFINE coordinates with ONE shared inversion (Montgomery's trick):
+//   forward   d_i = x2_i - x1_i,  pref_i = pref_{i-1} * d_i          (1 product; pref kept in global scratch)
+//   inversion inv = pref_B^-1                                          (Fermat: 380 squarings + ~190 products)
+//   backward  dinv_i = inv * pref_{i-1}, inv *= d_i, lambda = (y2 - y1) dinv_i, x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1
+//             (2 + 2 products + 1 squaring)
+// = 5 products + 1 squaring per addition + 570 / B for the inversion, against 8 + 2 for the XYZZ mixed addition — but the
+// operands and prefix products of a batch do not fit in registers: 112 B (x1, x2) + 56 B (pref) in the forward sweep, 224 + 56 B
+// read and 112 B written in the backward sweep = 560 B of memory traffic per addition, laid out [i][lane] (coalesced).
+// Values need not be curve points for timing; they are distinct so no exceptional case is hit.
+template <int B>
+__global__ void __launch_bounds__(64, 2) k_batch_affine_g1(const FqU *pts /* [4][B][threads]: x1, y1, x2, y2 */, FqU *pref, FqU *out, uint32_t *sink) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const FqU *x1 = pts, *y1 = pts + (size_t)B * T, *x2 = pts + 2 * (size_t)B * T, *y2 = pts + 3 * (size_t)B * T;
+    FqU acc = FqU::one();
+    for (int i = 0; i < B; i++) {
+        const FqU d = fqu_sub<32>(x2[(size_t)i * T + t], x1[(size_t)i * T + t]);
+        pref[(size_t)i * T + t] = acc;
+        acc = fqu_mul(acc, d);
+    }
+    FqU inv = fqu_inv(acc);
+    for (int i = B - 1; i >= 0; i--) {
+        const FqU a = x1[(size_t)i * T + t], b = y1[(size_t)i * T + t], c = x2[(size_t)i * T + t], e = y2[(size_t)i * T + t];
+        const FqU d = fqu_sub<32>(c, a);
+        const FqU dinv = fqu_mul(inv, pref[(size_t)i * T + t]);
+        inv = fqu_mul(inv, d);
+        const FqU lam = fqu_mul(fqu_sub<32>(e, b), dinv);
+        const FqU x3 = fqu_sub<32>(fqu_sqr(lam), fqu_add(a, c));
+        const FqU y3 = fqu_sub<32>(fqu_mul(lam, fqu_sub<64>(a, x3)), b);
+        out[(size_t)(2 * i) * T + t] = x3;
+        out[(size_t)(2 * i + 1) * T + t] = y3;
+    }
+    sink[t] = inv.l[0];
+}
+__global__ void k_fill_fqu(FqU *p, size_t n, uint32_t seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = seed + (uint32_t)i * 2654435761u;
+    FqU v;
+    for (int k = 0; k < 14; k++) { s = s * 1664525u + 1013904223u; v.l[k] = (s >> 3) & (k == 13 ? 0xffu : FqU::MASK); }
+    p[i] = v;
+}
+template <int B>
+static int run_batch_affine() {
+    const size_t T = (size_t)256 * 4 * 2 * 64;      // one resident round at 2 waves per SIMD, as the accumulation kernel
+    FqU *pts, *pref, *out;
+    uint32_t *sink;
+    CHK(hipMalloc(&pts, 4 * (size_t)B * T * sizeof(FqU)));
+    CHK(hipMalloc(&pref, (size_t)B * T * sizeof(FqU)));
+    CHK(hipMalloc(&out, 2 * (size_t)B * T * sizeof(FqU)));
+    CHK(hipMalloc(&sink, T * sizeof(uint32_t)));
+    const size_t np = 4 * (size_t)B * T;
+    hipLaunchKernelGGL(k_fill_fqu, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, pts, np, 12345u);
+    hipLaunchKernelGGL(k_batch_affine_g1<B>, dim3((unsigned)(T / 64)), dim3(64), 0, 0, pts, pref, out, sink);
+    CHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, 0));
+    const int reps = 3;
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_batch_affine_g1<B>, dim3((unsigned)(T / 64)), dim3(64), 0, 0, pts, pref, out, sink);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double adds = (double)B * T * reps;
+    printf("batched affine G1  B=%-5d lanes=%zu  %8.3f ms  %7.3f G additions/s   (%.0f B of traffic per addition -> %.2f TB/s)\n", B, T, ms / reps,
+           adds / (ms * 1e-3) * 1e-9, 560.0, adds * 560.0 / (ms * 1e-3) * 1e-12);
+    hipFree(pts); hipFree(pref); hipFree(out); hipFree(sink);
+    return 0;
+}
+
 template <class K>
 static int run(const char *name, K kernel, double ops_per_thread, int blocks_per_cu, uint32_t *d_out) {
     const int cus = 256;
@@ -224,6 +295,10 @@ int main() {
         run("madd G1 (64thr blk)", k_madd<FqU>, (double)(ITERS / 64), b, d_out);
         run("madd G2 (64thr blk)", k_madd<Fq2U>, (double)(ITERS / 64), b, d_out);
     }
+    run_batch_affine<16>();
+    run_batch_affine<64>();
+    run_batch_affine<256>();
+    run_batch_affine<1024>();
     for (int b : {1, 2, 4, 8}) {
         run("Fq mul (call)", k_fq_mul, muls, b, d_out);
         run("Fq mul (inline)", k_fq_mul_inline, muls, b, d_out);
