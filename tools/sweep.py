@@ -1,7 +1,9 @@
 """In-process counterpart of the reference's sweep drivers (bench/matrix.py:10-60: all-ones matrices of size 2^k, prove
 then verify; bench/fibo.py:26-60: Fibonacci rounds 0..186 with a = 0, b = 1), through the handler mirrors instead of
 HTTP.  Records the reference's fields: num_constraints, setup_time, proving_time, verifying_time (seconds).
-    python tools/sweep.py matrix [max_power=6]     |     python tools/sweep.py fib [step=31]"""
+bench/prime.py:17-70: random x of 2, 4, .. 64 bits, i = 32 candidates, retried until a prime is found, prove then verify
+with the returned pvk.
+    python tools/sweep.py matrix [max_power=6]   |   python tools/sweep.py fib [step=31]   |   python tools/sweep.py prime [per_size=2]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +25,24 @@ if kind == "matrix":
         v = handlers.verify_proof(res["vk"], res["_circuit"].public_inputs, res["proof"])
         print("%d,%d,%.4f,%.4f,%.5f,%.5f,%s" % (n, res["num_constraints_circuit"], t1 - t0, res["setup_time"], res["proving_time"],
                                                v["verifying_time"], v["valid"]), flush=True)
+elif kind == "prime":
+    import random
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    rng = random.Random(2024)
+    print("x_bits,x,j,prime_num,num_constraints,num_variables,request_time,setup_time,proving_time,verifying_time,valid")
+    for k in range(1, 7):
+        bits = 1 << k
+        for _ in range(per):
+            while True:
+                x = rng.randint(1 << (bits // 2), (1 << bits) - 1 - (32 if bits == 64 else 0))
+                t0 = time.perf_counter()
+                res = handlers.prove_prime(dev, x, 32)
+                t1 = time.perf_counter()
+                if res["found_prime"]:
+                    break
+            v = handlers.verify_prime(res["pvk"], x, res["j"], res["proof"])
+            print("%d,%d,%d,%s,%d,%d,%.4f,%.4f,%.5f,%.5f,%s" % (bits, x, res["j"], res["prime_num"], res["num_constraints"], res["num_variables"],
+                                                             t1 - t0, res["setup_time"], res["proving_time"], v["verifying_time"], v["valid"]), flush=True)
 else:
     step = int(sys.argv[2]) if len(sys.argv) > 2 else 31
     print("num_of_rounds,num_constraints,request_time,setup_time,proving_time,verifying_time,valid")
