@@ -371,6 +371,85 @@ def test_rank_roles_partial_finish_equals_single_proof(dev, oracle, ranks, h_ran
         f(hnd)
 
 
+@pytest.mark.parametrize("cz,ch", [(0, 0), (17, 17), (9, 12), (22, 23), (17, -1), (-1, 19), (24, 20)])
+def test_window_tables_same_proof(dev, oracle, cz, ch):
+    """zkg16_pk_precompute: window tables 2^(c w) * base next to every base of the five queries, all digits of a scalar in ONE bucket
+    set.  The proof must be the plain key's proof == the oracle's, bit for bit, for widths on both sides of the two- / three-pass
+    scatter (<= 20 / > 20 bucket bits), for one side only, and for the default (no table below 2^17 terms).  A shard cut out of a
+    key with tables sees level 0 = the plain query; a shard gets its own tables; a second precompute is refused."""
+    from zksnark_finalproject_amd import Zkg16Error
+    from zksnark_finalproject_amd.device import shard_plan
+    rng = random.Random(977 + 31 * cz + ch)
+    nc, ni, nv = 6000, 3, 5200
+    A, B, C, z = synth.random_r1cs(rng, nc, ni, nv)
+    for i in range(ni, nv, 3):                     # the reference's witnesses are full of 0 / 1 / small values: giant buckets
+        z[i] = (0, 1, 1, 2, 255)[i % 5]
+    r1cs = synth.r1cs_arrays(A, B, C, ni)
+    pk, _ = synth.make_pk(oracle, r1cs, nv, rng, point_gen=dev.fixed_base)
+    zm = fr_mont_vec(z)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    ph, rh, wh = dev.pk_load(pk, ni), dev.r1cs_load(r1cs, nv), dev.witness_load(zm)
+    plain = dev.prove_resident(ph, rh, wh, r, s)
+    eproof, einf = oracle.prove(pk, r, s, r1cs, zm)
+    assert np.array_equal(plain[0], eproof) and np.array_equal(plain[1], einf)
+    added = dev.pk_precompute(ph, cz, ch)
+    n_h = (1 << 13) - 1
+    want = sum((254 // c) * n * sz for c, n, sz in ((cz, nv + 3, 3 * 112 + 224), (ch, n_h, 112)) if c > 0)
+    assert added == want                          # 0 for the default widths: both queries are far below 2^17 terms
+    tabled = dev.prove_resident(ph, rh, wh, r, s)
+    assert np.array_equal(tabled[0], plain[0]) and np.array_equal(tabled[1], plain[1])
+    if cz > 0 or ch > 0:
+        with pytest.raises(Zkg16Error) as e:
+            dev.pk_precompute(ph, cz, ch)
+        assert e.value.status == 1
+    # rank roles on top: shards of the tabled key, every other one with tables of its own
+    plan, _ = shard_plan(3, nv, n_h, 0.0, 2)
+    parts, pinf = [], []
+    for i, (z_lo, z_hi, h_lo, h_hi, blind) in enumerate(plan):
+        sh = dev.pk_slice(ph, z_lo, z_hi, h_lo, h_hi, blind)
+        if i != 1:
+            dev.pk_precompute(sh, 11 + i, 10)
+        pp, ff = dev.prove_partial(sh, rh, wh, r, s)
+        parts.append(pp)
+        pinf.append(ff)
+        dev.pk_free(sh)
+    fin = dev.prove_finish(ph, r, s, np.array(parts), np.array(pinf))
+    assert np.array_equal(fin[0], plain[0]) and np.array_equal(fin[1], plain[1])
+    with pytest.raises(Zkg16Error) as e:
+        dev.pk_precompute(987654, 0, 0)
+    assert e.value.status == 6
+    with pytest.raises(Zkg16Error) as e:
+        dev.pk_precompute(ph, 25, 0)
+    assert e.value.status == 1
+    for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(hnd)
+
+
+@pytest.mark.parametrize("kind", ["matrix32", "prime"])
+def test_window_tables_reference_circuits(dev, oracle, kind):
+    """The default table widths on the reference's circuits at BASELINE's 32x32 size and on PrimeCircuit (bit-valued witnesses:
+    almost every term falls into bucket 1 of window 0): same proof as the plain key, and it verifies."""
+    from zksnark_finalproject_amd import circuits
+    from zksnark_finalproject_amd.device import verify
+    import bench
+    if kind == "prime":
+        c = circuits.prime_circuit(5, 32)
+    else:
+        c, _, _ = bench.synthesize("matrix", 32)
+    trap, g1, g2 = bench.draw_key_inputs(11)
+    rh = dev.r1cs_load(c.r1cs, c.num_vars)
+    ph, vk = dev.setup_resident(rh, c.num_instance, trap, g1, g2)
+    wh = dev.witness_load(c.z)
+    r, s = fr_mont(1234567), fr_mont(7654321)
+    plain = dev.prove_resident(ph, rh, wh, r, s)
+    assert dev.pk_precompute(ph) > 0
+    tabled = dev.prove_resident(ph, rh, wh, r, s)
+    assert np.array_equal(tabled[0], plain[0]) and np.array_equal(tabled[1], plain[1])
+    assert verify(vk, c.public_inputs, *tabled)
+    for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(hnd)
+
+
 def test_prime_handler_round_trip(dev):
     """prove_prime / verify_prime mirrors (backend/prime_snark.rs:49-146, 165-206): search, PrimeCircuit, device setup, device proof,
     pairing verification through the wire format with the public inputs recovered by re-synthesis; a wrong j does not verify."""

@@ -1,5 +1,6 @@
 """A/B library options in one process (development probe, GPU box):
-   python tools/ab_option.py <matrix_n> <opt=v0,v1,...> [<opt2=...> ...]     (options are swept one at a time, the others at 0/default)"""
+   python tools/ab_option.py <matrix_n> [tables=CZ,CH] <opt=v0,v1,...> [<opt2=...> ...]     (options are swept one at a time, the others
+   at 0/default; tables=: window tables first, 0 = default widths)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,6 +10,8 @@ from zksnark_finalproject_amd import Device
 from zksnark_finalproject_amd.device import verify
 n = int(sys.argv[1])
 sweeps = [(a.split("=")[0], [int(x) for x in a.split("=")[1].split(",")]) for a in sys.argv[2:]]
+tables = [v for k, v in sweeps if k == "tables"]
+sweeps = [(k, v) for k, v in sweeps if k != "tables"]
 dev = Device(0)
 trap, g1, g2 = bench.draw_key_inputs(7)
 c, _, desc = bench.synthesize("matrix", n)
@@ -18,6 +21,8 @@ wh = dev.witness_load(c.z)
 r, s = bench.fr_mont(12345), bench.fr_mont(67890)
 ref = dev.prove_resident(ph, rh, wh, r, s)
 print(desc, "verified:", verify(vk, c.public_inputs, *ref), flush=True)
+if tables:
+    print("window tables: %.2f GB" % (dev.pk_precompute(ph, *tables[0]) / 1e9), flush=True)
 reps = 3 if n >= 100 else 5
 for opt, vals in sweeps:
     res = {v: [] for v in vals}

@@ -254,6 +254,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     out.h = out.l = out.a = out.b1 = G1XYZZ::inf();
     out.b2 = G2XYZZ::inf();
     ZK_HIP(hipEventRecord(ev[0], ctx->stream));
+    const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
+    MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
+    const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
     if (z_side) {
         if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
         Fr *extra = reinterpret_cast<Fr *>(ctx->extra_host);
@@ -263,21 +266,22 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         // the digit kernel reads the three extra scalars straight from this pinned (device-visible) host buffer: no host-to-device
         // copy is queued; the buffer is rewritten only by the next proof, which starts after this one has been collected
         ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, extra, 3, true, nullptr};
-        msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z);
+        const int tz = pk.tab_c_z;
+        msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z, tz, tz != 0);
         if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
             zsrc.mask = pk.b_mask.as<uint8_t>();
-            msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb);
+            msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb, tz, tz != 0);
         }
     }
     ZK_HIP(hipEventRecord(ev[1], ctx->stream));
-
-    const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
-    MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
-    const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
     // ---- the four z-side accumulations go onto the main stream BEFORE the witness map's ~40 launches (G2 first: its long
     // reduction then hides behind the G1 accumulations); their reductions — whose first packet is a wait — only after those
     // launches (msm_enqueue_reduce).  Kernel trace at n = 32: queued after the witness map, the G2 accumulation started
     // 2.0 ms into the proof with its inputs ready at 0.6 ms.
+    // (Tried and dropped, 128x128: sorting the B-side list first and the full list on another stream underneath the G2
+    // accumulation, with the witness map held back until the first list exists — the accumulation then starts 9 instead of
+    // 15 ms into the proof, and the proof takes the same 171-172 ms: kernels that share the device slow each other by about
+    // what the overlap saves, the proof is the SUM of its kernels' work.  A high-priority witness-map stream: +1 ms.)
     if (z_side) {
         msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
         msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
@@ -299,7 +303,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         ZK_HIP(hipEventRecord(ev[3], ctx->stream));
         if (nh) {
             const ScalarSrc hsrc{h + pk.h_lo, nh, nullptr, 0, true, nullptr};
-            msm_plan_build(ctx, ctx->ws_h, hsrc, plan_h, ctx->opt_window_bits_h);
+            msm_plan_build(ctx, ctx->ws_h, hsrc, plan_h, pk.tab_c_h ? pk.tab_c_h : ctx->opt_window_bits_h, pk.tab_c_h != 0);
         }
         ZK_HIP(hipEventRecord(ev[4], ctx->stream));
     } catch (...) {
@@ -858,6 +862,55 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
     }
     if (h_ranks_out) *h_ranks_out = k;
     return ZKG16_OK;
+}
+
+// Window tables for a resident key or shard (msm.hip, "window tables").  window_bits_* = 0: chosen from the query length;
+// < 0: leave that side as it is.  All four z-side queries share one width (A and L share a sorted term list, so do B1 and B2).
+// Width chosen by a cost model in mixed additions: one per (scalar, window) term plus ~7 per bucket (its two additions of
+// the reduction, the lost first slot of its run, its share of the fix-ups), over the widths that end on a window boundary
+// (15, 14, 13, 12 windows).  Measured (ms per proof, plain key -> table): 32x32 13.4 -> 12.05 at 17 bits (13.15 at 19, 14.0 at
+// 20); 46x46 22.6 -> 19.65 at 17 (21.7 at 19); 128x128 181 -> 171.0 at 20 / 22 for z / h (172.0 at 20 / 20, 172.4 at 22 / 22,
+// 176.4 at 19 / 22).  Below 17 bits a bucket run spans more than the four lanes the short fix-up path handles (one resident round
+// of accumulation waves is 2^17 lanes) and everything goes through the long path: 46x46 at 16 bits 27.8 ms, at 15 bits 40 ms.
+// Queries under 2^17 terms get no table by default: there the proof is a chain of latency-bound kernels either way.
+static int default_table_bits(size_t n) {
+    if (n < ((size_t)1 << 17)) return 0;
+    int best = 17;
+    double best_cost = 0;
+    for (int c : {17, 19, 20, 22}) {
+        const double cost = (double)n * (254 / c + 1) + 7.0 * (double)((size_t)1 << (c - 1));
+        if (c == 17 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+int zkg16_pk_precompute(zkg16_ctx *ctx, uint64_t pk_handle, int window_bits_z, int window_bits_h, uint64_t *table_bytes) {
+    if (window_bits_z > 24 || window_bits_h > 24 || (window_bits_z > 0 && window_bits_z < 4) || (window_bits_h > 0 && window_bits_h < 4))
+        return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    if (!pk) return ZKG16_ERR_BAD_HANDLE;
+    if ((window_bits_z >= 0 && pk->tab_c_z) || (window_bits_h >= 0 && pk->tab_c_h)) return ZKG16_ERR_BAD_ARG;      // already built
+    const size_t nz = pk->z_hi - pk->z_lo, nzs = nz + 3, nh = pk->h_hi - pk->h_lo;
+    const int cz = window_bits_z < 0 || (nz == 0 && !pk->blinding) ? 0 : window_bits_z ? window_bits_z : default_table_bits(nzs);
+    const int ch = window_bits_h < 0 || nh == 0 ? 0 : window_bits_h ? window_bits_h : default_table_bits(nh);
+    if ((cz && nzs * (size_t)(254 / cz + 1) >= ((size_t)1 << 31)) || (ch && nh * (size_t)(254 / ch + 1) >= ((size_t)1 << 31))) return ZKG16_ERR_BAD_ARG;
+    uint64_t added = 0;
+    if (cz) {
+        DevBuf a = msm_tables_build_g1(ctx, pk->a, nzs, cz);
+        DevBuf l = msm_tables_build_g1(ctx, pk->l, nzs, cz);
+        DevBuf b1 = msm_tables_build_g1(ctx, pk->b1, nzs, cz);
+        DevBuf b2 = msm_tables_build_g2(ctx, pk->b2, nzs, cz);
+        pk->a = std::move(a); pk->l = std::move(l); pk->b1 = std::move(b1); pk->b2 = std::move(b2);      // all four or none
+        pk->tab_c_z = cz;
+        added += (uint64_t)(254 / cz) * nzs * (3 * sizeof(G1AffineU) + sizeof(G2AffineU));
+    }
+    if (ch) {
+        pk->h = msm_tables_build_g1(ctx, pk->h, nh, ch);
+        pk->tab_c_h = ch;
+        added += (uint64_t)(254 / ch) * nh * sizeof(G1AffineU);
+    }
+    if (table_bytes) *table_bytes = added;
+    ZK_API_END(ctx)
 }
 
 void zkg16_pk_free(zkg16_ctx *ctx, uint64_t h) {

@@ -4,7 +4,8 @@
 //
 // The digit kernel (msm.hip) leaves one 32-bit code per (window, scalar): (|d| - 1) << 1 | negate, or ~0 for digit 0.
 // Within a window the entries must end up ordered by bucket = |d| - 1 (c - 1 bits); windows are independent, so the
-// window index is never part of a key.  Two stable least-significant-digit passes over the bucket bits (<= 10 bits each):
+// window index is never part of a key.  Stable least-significant-digit passes over the bucket bits: two of <= 10 bits up to
+// 20 bucket bits, three of <= 8 bits above (the 21-bit buckets of a key with window tables, msm_tables_build):
 //
 //   count    one workgroup (4 waves) per 4096 consecutive elements of a window: per-WAVE digit histograms in LDS, no atomics —
 //            the lanes holding the same digit find each other with one __ballot per digit bit (wave64 "match"), the lowest
@@ -19,7 +20,7 @@
 //
 // Everything is deterministic and stable (original index order inside a bucket): no atomics on positions, so every
 // intermediate bucket sum of the accumulation is reproducible run to run.  Zero digits are dropped in the first pass, the
-// second pass writes the final entry list compactly over all windows: entries[k] = (index << 1 | negate, global bucket id).
+// last pass writes the final entry list compactly over all windows: entries[k] = (index << 1 | negate, global bucket id).
 // Traffic per (scalar, window): 4 B digit code written once and read twice, 8 B entry written twice and read twice = 44 B
 // against ~64 B for three onesweep passes over 64-bit keys; the arithmetic is ~1 VALU instruction per element per pass.
 #include "common.hpp"
@@ -33,16 +34,16 @@ static constexpr int SORT_BCH = SORT_WCH * SORT_WAVES;       // elements per wor
 static constexpr int SORT_MAX_BITS = 10;         // digit bits per pass
 
 struct SortPass {
-    const uint32_t *codes;       // pass 0 input: digit codes [window][n]
-    const uint2 *in;             // pass 1 input: [window * n + k], k < in_count[window]
+    const uint32_t *codes;       // first pass input: digit codes [window][n]
+    const uint2 *in;             // later passes' input: [window * n + k], k < in_count[window]
     uint2 *out;
     uint32_t *counts;            // [window][digit][block]  (after `scan`: exclusive prefix over the blocks)
     uint32_t *dig_total;         // [window][digit]
     uint32_t *win_total;         // [window]: elements of this pass's output per window (sort_window_total_kernel)
-    const uint32_t *in_count;    // pass 1: elements per window in `in` (= pass 0's win_total); pass 0: null (n each)
+    const uint32_t *in_count;    // later passes: elements per window in `in` (= the previous pass's win_total); first pass: null (n each)
     size_t n;                    // scalars per window
     uint32_t nblk;               // workgroups per window = ceil(n / SORT_BCH)
-    uint32_t nb;                 // buckets per window (pass 1 writes global bucket ids)
+    uint32_t nb;                 // buckets per window (the last pass writes global bucket ids)
     int nwin, shift, bits, pass;
 };
 
@@ -65,11 +66,11 @@ __device__ __forceinline__ void wave_sync() {                           // lanes
 }
 
 // element k of a window: digit of this pass + the entry it becomes (bucket id still window-local)
-template <int PASS>
+template <bool FIRST>
 __device__ __forceinline__ bool sort_fetch(const SortPass &a, uint32_t w, size_t k, size_t limit, uint32_t &dg, uint2 &elem) {
     const uint32_t mask = (1u << a.bits) - 1u;
     if (k >= limit) return false;
-    if (PASS == 0) {
+    if (FIRST) {
         const uint32_t code = a.codes[(size_t)w * a.n + k];
         if (code == 0xffffffffu) return false;                 // digit 0: no entry
         elem = make_uint2(((uint32_t)k << 1) | (code & 1u), code >> 1);
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool sort_fetch(const SortPass &a, uint32_t w, size_t
 
 // per-wave digit histogram of the block's chunk in hist[wave][digit]; returns through el/dgv/rk the elements this lane
 // holds, their digits and their rank among the equal digits of the same WAVE (original index order)
-template <int PASS, bool KEEP>
+template <bool FIRST, bool KEEP>
 __device__ __forceinline__ void sort_sweep(const SortPass &a, uint32_t w, size_t limit, uint32_t *hist, uint2 *el, uint32_t *dgv, uint32_t *rk,
                                             uint32_t &validmask) {
     const uint32_t lane = threadIdx.x & 63u, slot = threadIdx.x >> 6;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void sort_sweep(const SortPass &a, uint32_t w, size_t
     for (int r = 0; r < SORT_ROUNDS; r++) {
         uint32_t dg = 0;
         uint2 e = make_uint2(0, 0);
-        const bool valid = sort_fetch<PASS>(a, w, k0 + (size_t)r * 64 + lane, limit, dg, e);
+        const bool valid = sort_fetch<FIRST>(a, w, k0 + (size_t)r * 64 + lane, limit, dg, e);
         const uint64_t peers = match_digit(dg, valid, a.bits);
         const uint32_t below = lanes_below(peers);
         uint32_t old = 0;
@@ -114,13 +115,13 @@ __device__ __forceinline__ void sort_sweep(const SortPass &a, uint32_t w, size_t
     }
 }
 
-template <int PASS>
+template <bool FIRST>
 __global__ void __launch_bounds__(64 * SORT_WAVES) sort_count_kernel(SortPass a) {
     extern __shared__ uint32_t sort_smem[];
     const uint32_t w = blockIdx.y, ndig = 1u << a.bits;
-    const size_t limit = PASS == 0 ? a.n : (size_t)a.in_count[w];
+    const size_t limit = FIRST ? a.n : (size_t)a.in_count[w];
     uint32_t vm;
-    sort_sweep<PASS, false>(a, w, limit, sort_smem, nullptr, nullptr, nullptr, vm);
+    sort_sweep<FIRST, false>(a, w, limit, sort_smem, nullptr, nullptr, nullptr, vm);
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < ndig; d += blockDim.x) {
         uint32_t t = 0;
@@ -183,7 +184,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *scratc
 
 // the block ranks its chunk (sweep), orders it by digit in LDS, and writes every digit's run with consecutive lanes on
 // consecutive entries: runs average chunk / 2^bits entries (16 x 8 B at 8 bits), so the stores leave as whole cache lines
-template <int PASS>
+template <bool FIRST, bool LAST>
 __global__ void __launch_bounds__(64 * SORT_WAVES) sort_scatter_kernel(SortPass a) {
     extern __shared__ uint32_t sort_smem[];
     const uint32_t w = blockIdx.y, ndig = 1u << a.bits, tid = threadIdx.x, slot = tid >> 6;
@@ -191,15 +192,15 @@ __global__ void __launch_bounds__(64 * SORT_WAVES) sort_scatter_kernel(SortPass 
     uint32_t *gdelta = hist + SORT_WAVES * ndig;                 // [ndig]: global position minus local position of a digit's run
     uint32_t *scratch = gdelta + ndig;                           // [2 * SORT_WAVES]
     uint2 *stage = reinterpret_cast<uint2 *>(scratch + 2 * SORT_WAVES);      // [SORT_BCH]
-    const size_t limit = PASS == 0 ? a.n : (size_t)a.in_count[w];
+    const size_t limit = FIRST ? a.n : (size_t)a.in_count[w];
     if ((size_t)blockIdx.x * SORT_BCH >= limit) return;          // uniform over the block
     uint2 el[SORT_ROUNDS];
     uint32_t dgv[SORT_ROUNDS], rk[SORT_ROUNDS], vm;
-    sort_sweep<PASS, true>(a, w, limit, hist, el, dgv, rk, vm);
+    sort_sweep<FIRST, true>(a, w, limit, hist, el, dgv, rk, vm);
     __syncthreads();
-    // window base: pass 0 keeps windows apart (w * n), pass 1 packs them (sum of the totals of the windows before)
-    size_t win_base = PASS == 0 ? (size_t)w * a.n : 0;
-    if (PASS == 1)
+    // window base: the last pass packs the windows (sum of the totals of the windows before), the others keep them apart (w * n)
+    size_t win_base = LAST ? 0 : (size_t)w * a.n;
+    if (LAST)
         for (uint32_t x = 0; x < w; x++) win_base += a.win_total[x];
     // digits are handled `per` at a time per thread, in digit order, so one block scan gives the local start of every digit
     // (from the block's own counts) and a second one the global start (from the totals of the whole window)
@@ -234,11 +235,11 @@ __global__ void __launch_bounds__(64 * SORT_WAVES) sort_scatter_kernel(SortPass 
     for (int r = 0; r < SORT_ROUNDS; r++)
         if (vm & (1u << r)) stage[hist[slot * ndig + dgv[r]] + rk[r]] = el[r];
     __syncthreads();
-    const uint32_t mask = ndig - 1u, add = PASS == 1 ? w * a.nb : 0u;
+    const uint32_t mask = ndig - 1u, add = LAST ? w * a.nb : 0u;
     for (uint32_t i = tid; i < block_count; i += blockDim.x) {
         uint2 e = stage[i];
         const uint32_t d = (e.y >> a.shift) & mask;
-        e.y += add;                                              // pass 1: global bucket id
+        e.y += add;                                              // last pass: global bucket id
         a.out[gdelta[d] + i] = e;
     }
 }
@@ -253,18 +254,20 @@ static size_t sort_lds_bytes(int bits, bool scatter) {
 const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t *codes, size_t n, int nwin, int c, uint2 *entries) {
     if (n == 0) return nullptr;
     const int bbits = c - 1;                                   // bucket bits per window
-    const int bits0 = (bbits + 1) / 2;
-    const int bits1 = bbits - bits0;
-    if (bits0 > SORT_MAX_BITS || bits1 > SORT_MAX_BITS || bits1 < 0) throw HipError{hipErrorInvalidValue, "bucket sort: window bits above build limit", __FILE__, __LINE__};
+    const int npass = bbits <= 2 * SORT_MAX_BITS ? 2 : 3;      // 2 x <= 10 bits; above 20 bucket bits 3 x <= 8
+    if (bbits > 24 || n >= ((size_t)1 << 31)) throw HipError{hipErrorInvalidValue, "bucket sort: window bits / length above build limit", __FILE__, __LINE__};
+    int bits[3] = {0, 0, 0};
+    for (int p = 0; p < npass; p++) bits[p] = bbits / npass + (p < bbits % npass ? 1 : 0);
     const uint32_t nblk = (uint32_t)((n + SORT_BCH - 1) / SORT_BCH);
-    const size_t ndig_max = (size_t)1 << (bits0 > bits1 ? bits0 : bits1);
+    const size_t ndig_max = (size_t)1 << bits[0];
     const size_t counts_words = (size_t)nwin * ndig_max * nblk;
-    const size_t small = (size_t)nwin * ndig_max + 2 * (size_t)nwin + 16;
+    const size_t small = (size_t)nwin * ndig_max + 3 * (size_t)nwin + 16;
     ws.sort_temp.ensure((counts_words + small) * sizeof(uint32_t));
     ws.keys.ensure((size_t)nwin * n * sizeof(uint2));           // intermediate entry list (window w at [w * n, ...))
+    if (npass == 3) ws.stage.ensure((size_t)nwin * n * sizeof(uint2));      // second intermediate list
     uint32_t *counts = ws.sort_temp.as<uint32_t>();
     uint32_t *dig_total = counts + counts_words;
-    uint32_t *win0 = dig_total + (size_t)nwin * ndig_max, *win1 = win0 + nwin;
+    uint32_t *win_tot = dig_total + (size_t)nwin * ndig_max;     // [pass][window]
     SortPass a{};
     a.codes = codes;
     a.counts = counts;
@@ -275,26 +278,26 @@ const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t
     a.nwin = nwin;
     const dim3 grid(nblk, (unsigned)nwin), block(64 * SORT_WAVES);
     ScopedKernelTimer kt(ctx, "msm_bucket_sort", (double)n * nwin, ctx->stream);
-    // pass 0: low bits of the bucket; codes -> intermediate list
-    a.pass = 0; a.shift = 0; a.bits = bits0;
-    a.out = ws.keys.as<uint2>();
-    a.win_total = win0;
-    hipLaunchKernelGGL(sort_count_kernel<0>, grid, block, sort_lds_bytes(bits0, false), ctx->stream, a);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1u << bits0, (unsigned)nwin), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(sort_window_total_kernel, dim3((unsigned)nwin), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(sort_scatter_kernel<0>, grid, block, sort_lds_bytes(bits0, true), ctx->stream, a);
-    // pass 1: high bits; intermediate list -> entries (global bucket ids, compact over the windows)
-    a.pass = 1; a.shift = bits0; a.bits = bits1;
-    a.in = ws.keys.as<uint2>();
-    a.in_count = win0;
-    a.out = entries;
-    a.win_total = win1;
-    hipLaunchKernelGGL(sort_count_kernel<1>, grid, block, sort_lds_bytes(bits1, false), ctx->stream, a);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1u << bits1, (unsigned)nwin), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(sort_window_total_kernel, dim3((unsigned)nwin), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(sort_scatter_kernel<1>, grid, block, sort_lds_bytes(bits1, true), ctx->stream, a);
+    int shift = 0;
+    for (int p = 0; p < npass; p++) {
+        const bool first = p == 0, last = p == npass - 1;
+        a.pass = p; a.shift = shift; a.bits = bits[p];
+        a.in = first ? nullptr : (p == 1 ? ws.keys.as<uint2>() : ws.stage.as<uint2>());
+        a.in_count = first ? nullptr : win_tot + (size_t)(p - 1) * nwin;
+        a.out = last ? entries : (p == 0 ? ws.keys.as<uint2>() : ws.stage.as<uint2>());
+        a.win_total = win_tot + (size_t)p * nwin;
+        const size_t lds_c = sort_lds_bytes(bits[p], false), lds_s = sort_lds_bytes(bits[p], true);
+        if (first) hipLaunchKernelGGL(sort_count_kernel<true>, grid, block, lds_c, ctx->stream, a);
+        else hipLaunchKernelGGL(sort_count_kernel<false>, grid, block, lds_c, ctx->stream, a);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1u << bits[p], (unsigned)nwin), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(sort_window_total_kernel, dim3((unsigned)nwin), dim3(64), 0, ctx->stream, a);
+        if (first) hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, block, lds_s, ctx->stream, a);
+        else if (last) hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, block, lds_s, ctx->stream, a);
+        else hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, block, lds_s, ctx->stream, a);
+        shift += bits[p];
+    }
     ZK_HIP(hipGetLastError());
-    return win1;
+    return win_tot + (size_t)(npass - 1) * nwin;
 }
 
 }  // namespace zk

@@ -103,6 +103,9 @@ struct PkDev {              // proving key shard resident in HBM (affine AoS; (0
     G2Affine beta_g2, delta_g2;
     bool blinding = true;                            // this shard's MSMs carry the r*delta, s*delta, -rs*delta terms
     bool full = true;                                // whole key (all ranges + blinding terms): zkg16_prove / _resident
+    // window tables (zkg16_pk_precompute): a / b1 / l / b2 hold [254 / tab_c_z + 1][z_hi - z_lo + 3] points, h [254 / tab_c_h + 1][n_h];
+    // level 0 is the query itself, so everything that reads the plain query keeps working.  0 = no table.
+    int tab_c_z = 0, tab_c_h = 0;
 };
 
 struct R1csDev {
@@ -210,7 +213,9 @@ void witness_map_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr **h_out);
 // Scalar-vector side of Pippenger (shared by every MSM over the same scalars).
 struct MsmPlan {
     size_t n = 0;            // scalars
-    int c = 0, nwin = 0;     // window bits, window count
+    int c = 0, nwin = 0;     // window bits, window count (bucket sets: 1 with window tables)
+    int nwin_digits = 0;     // digits per scalar = 254 / c + 1 (= nwin without tables)
+    bool tabled = false;     // the bases are a window table [nwin_digits][n] (msm_tables_build): every digit lands in ONE bucket set
     size_t nb = 0;           // buckets per window = 2^(c-1)
     size_t total_entries = 0;            // upper bound n * windows (the exact count lives on the device)
     uint32_t lanes_g1 = 0, lanes_g2 = 0; // lanes of one resident round of accumulation waves (2 / 1 waves per SIMD)
@@ -219,7 +224,10 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
 // The scalar vector where it lives: n_main elements at `main` then n_extra at `extra`; `mont` = arkworks' Montgomery form
 // (converted inside the digit kernel); mask[i] != 0 zeroes scalar i (B-query density filter).  All device pointers.
 struct ScalarSrc { const Fr *main; size_t n_main; const Fr *extra; size_t n_extra; bool mont; const uint8_t *mask; };
-void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits = 0);
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits = 0, bool tabled = false);
+// window tables of a resident key: bases[n] -> new buffer [254 / c + 1][n], level w = 2^(c w) * base (msm.hip)
+DevBuf msm_tables_build_g1(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c);
+DevBuf msm_tables_build_g2(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort; option sort_mode 1)
 // bucket_sort.hip: hand-written wave-ballot counting scatter (default); returns the per-window entry counts (device)
 const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t *codes, size_t n, int nwin, int c, uint2 *entries);

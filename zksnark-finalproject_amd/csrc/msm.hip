@@ -614,19 +614,26 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonica
     const ScalarSrc src{scalars_canonical, n, nullptr, 0, false, nullptr};
     msm_plan_build(ctx, ws, src, plan, window_bits);
 }
-void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits) {
+// tabled (window tables, msm_tables_build): the bases are [nwin_digits][n] with level w = 2^(c w) * base, so digit w of scalar i
+// is an ordinary term (base w * n + i, digit) of ONE bucket set — the digit codes [w][i] already are that flat term list, and
+// the scatter sees a single window of n * nwin_digits terms.  Fewer additions (larger c at the same bucket count) and one
+// bucket reduction instead of one per window.
+void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits, bool tabled) {
     const size_t n = src.n_main + src.n_extra;
     plan.n = n;
-    plan.c = (window_bits >= 2 && window_bits <= 20) ? window_bits : pick_window_bits(ctx, n);
-    plan.nwin = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
+    plan.tabled = tabled;
+    plan.c = (window_bits >= 2 && window_bits <= (tabled ? 24 : 20)) ? window_bits : pick_window_bits(ctx, n);
+    plan.nwin_digits = 254 / plan.c + 1;      // magnitudes are < 2^254 after the r - s fold (msm_digits_kernel)
+    plan.nwin = tabled ? 1 : plan.nwin_digits;
     plan.nb = (size_t)1 << (plan.c - 1);
     plan.total_entries = 0;
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
-    const size_t tot = n * (size_t)plan.nwin;
+    const size_t tot = n * (size_t)plan.nwin_digits;
+    if (tot >= ((size_t)1 << 31)) throw HipError{hipErrorInvalidValue, "msm: more than 2^31 (scalar, window) terms", __FILE__, __LINE__};
     ws.entries.ensure(tot * sizeof(uint64_t));
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
-    const bool own_sort = ctx->opt_sort_mode == 0;
+    const bool own_sort = ctx->opt_sort_mode == 0 || tabled;
     const DigitSrc d{reinterpret_cast<const uint32_t *>(src.main), reinterpret_cast<const uint32_t *>(src.extra), src.n_main, n, src.mask,
                      src.mont ? 1 : 0};
     const uint32_t *win_total = nullptr;
@@ -634,10 +641,11 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
         ws.codes.ensure(tot * sizeof(uint32_t));
         {
             ScopedKernelTimer kt(ctx, "msm_digits_kernel", (double)n, ctx->stream);
-            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin, plan.nb,
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, plan.c, plan.nwin_digits, plan.nb,
                                (uint64_t *)nullptr, ws.codes.as<uint32_t>(), (uint32_t)tb);
         }
-        win_total = msm_bucket_sort(ctx, ws, ws.codes.as<uint32_t>(), n, plan.nwin, plan.c, ws.entries.as<uint2>());
+        if (tabled) win_total = msm_bucket_sort(ctx, ws, ws.codes.as<uint32_t>(), tot, 1, plan.c, ws.entries.as<uint2>());
+        else win_total = msm_bucket_sort(ctx, ws, ws.codes.as<uint32_t>(), n, plan.nwin, plan.c, ws.entries.as<uint2>());
     } else {
         ws.keys.ensure(tot * sizeof(uint64_t));
         {
@@ -929,6 +937,46 @@ static void batch_affine_run(zkg16_ctx *ctx, const XYZZ<FU> *pts, size_t n, DevB
     hipLaunchKernelGGL(batch_affine_kernel<FU>, dim3(blocks), dim3(64), 0, ctx->stream, pts, n, pref.as<FU>(), segs);
     ZK_HIP(hipGetLastError());
 }
+
+// ------------------------------------------------------------------------------------------------ window tables
+// A resident key may carry, next to every base P_i, its multiples 2^(c w) P_i for the windows w = 1 .. nwin-1 (affine, same
+// unsaturated form): table[w][i].  A proof then needs no per-window bucket sets — digit w of scalar i is a term on base
+// table[w][i] of ONE set of 2^(c-1) buckets — so c can grow (22 bits, 12 digits per scalar instead of 15 at 17 bits) at an
+// unchanged bucket count, and the five reductions of a proof shrink to one window each.  Cost: nwin x the key in HBM
+// (128x128 circuit: 69 GB of the 288 GB) and c * (nwin - 1) doublings per base once, at key-load time (zkg16_pk_precompute).
+template <class FU>
+__global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2) table_level_kernel(const Affine<FU> *prev, XYZZ<FU> *out, size_t n, int c) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<FU> p = ldv(prev + i);
+    XYZZ<FU> acc = XYZZ<FU>::inf();
+    if (!p.is_inf()) {
+        acc = xyzz_dbl_affine(p);
+        for (int k = 1; k < c; k++) acc = xyzz_dbl(acc);
+    }
+    stv(out + i, acc);
+}
+template <class FU>
+static DevBuf tables_build(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c) {
+    const int nwin = 254 / c + 1;
+    const size_t lvl = n * sizeof(Affine<FU>);
+    DevBuf tab((size_t)nwin * lvl), xyzz(n * sizeof(XYZZ<FU>)), pref;
+    ZK_HIP(hipMemcpyAsync(tab.p, bases.p, lvl, hipMemcpyDeviceToDevice, ctx->stream));
+    Affine<FU> *t = tab.as<Affine<FU>>();
+    for (int w = 1; w < nwin; w++) {
+        hipLaunchKernelGGL(table_level_kernel<FU>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, t + (size_t)(w - 1) * n,
+                           xyzz.as<XYZZ<FU>>(), n, c);
+        ZK_HIP(hipGetLastError());
+        AffineSegs<FU> seg{};
+        seg.n = 1;
+        seg.out_u[0] = t + (size_t)w * n;
+        batch_affine_run<FU>(ctx, xyzz.as<XYZZ<FU>>(), n, pref, seg);
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return tab;
+}
+DevBuf msm_tables_build_g1(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c) { return tables_build<FqU>(ctx, bases, n, c); }
+DevBuf msm_tables_build_g2(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c) { return tables_build<Fq2U>(ctx, bases, n, c); }
 
 // [s_i] base for the n concatenated scalars; results split over `segs`
 template <class FU>

@@ -71,6 +71,13 @@ class Device:
             num_instance, z_lo, z_hi, h_lo, h_hi, int(bool(blinding)), C.byref(handle)))
         return handle.value
 
+    def pk_precompute(self, pk_h, window_bits_z=0, window_bits_h=0):
+        """Window tables for a key that stays resident (zkg16_pk_precompute): same proofs, fewer bucket additions.
+        0 = width chosen from the query length, < 0 = leave that side without a table.  -> HBM bytes added."""
+        added = C.c_uint64(0)
+        self._check(self.lib.zkg16_pk_precompute(self.ctx, pk_h, int(window_bits_z), int(window_bits_h), C.byref(added)))
+        return added.value
+
     def pk_slice(self, pk_h, z_lo, z_hi, h_lo, h_hi, blinding):
         """A shard cut out of a whole resident key, device to device (zkg16_pk_slice)."""
         handle = C.c_uint64()
