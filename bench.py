@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--h-ranks", type=int, default=0, help="N > 1, shard: ranks that run the witness map (0 = cost model; N = equal split)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="N = 1: after the timed region, also report throughput with this many proofs in flight (one ctx per host thread)")
+    ap.add_argument("--tables", default="auto", choices=["auto", "off"],
+                    help="auto = window tables for the resident key (zkg16_pk_precompute; the plain key is timed first and reported "
+                         "beside it); off = plain key only")
     ap.add_argument("--seed", type=int, default=2026)
     return ap.parse_args()
 
@@ -228,6 +231,27 @@ def main():
     rng = np.random.default_rng(99)
     rs = [(fr_mont(int.from_bytes(rng.bytes(31), "little")), fr_mont(int.from_bytes(rng.bytes(31), "little"))) for _ in range(args.steps + args.warmup + 2)]
 
+    def with_tables(d, pk_h, prove_once):
+        """Window tables for a key that stays resident; the plain key is timed first (a few proofs) so both appear in the line."""
+        if args.tables == "off":
+            return None
+        plain_ms = None
+        if prove_once is not None:
+            prove_once()
+            k = 3
+            t_ = time.perf_counter()
+            for _ in range(k):
+                prove_once()
+            plain_ms = (time.perf_counter() - t_) / k * 1e3
+        t_ = time.perf_counter()
+        added = d.pk_precompute(pk_h)
+        pre_s = time.perf_counter() - t_
+        bz, bh = d.pk_table_bits(pk_h)
+        return {"window_bits_z": bz, "window_bits_h": bh, "table_bytes": added, "precompute_s": pre_s, "plain_key_ms_per_proof": plain_ms,
+                "note": "zkg16_pk_precompute: 2^(c w) multiples of every base kept in HBM, all digits of a scalar in one bucket set per MSM; "
+                        "same proofs bit for bit (tests/test_gpu_parity.py::test_window_tables_*); built once per resident key"}
+    tables_info = with_tables(dev, ph, (lambda: dev.prove_resident(ph, rh, wh, *rs[0])) if world == 1 else None)
+
     xdev = "cuda" if on_gpu else "cpu"
     if sharded:
         gather_buf = [torch.empty(77, dtype=torch.int64, device=xdev) for _ in range(world)]
@@ -287,7 +311,7 @@ def main():
             gbs = 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9
             extra_out["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_cols_u + ntt_pass_rows_u (one coset-inverse transform of 2^%d)" % log_n,
                                          "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "ms": ntt_ms, "transforms_per_proof": 7,
-                                         "traffic": profile_lookup(["n%d" % args.matrix_n, "ntt_transform_traffic_bytes"]),
+                                         "traffic": profile_lookup(["n%d" % args.matrix_n, "ntt_transform_traffic_bytes"]),      # the transforms do not depend on the key's tables
                                          "note": "64 algorithmic bytes per element (read once, written once); integer-ALU bound too"}
             extra_out["witness_map_standalone_ms"] = dev.bench_witness_map(rh, wh, 3)
         except Exception as e:      # noqa: BLE001 - an extra leg must never cost the contract line
@@ -375,6 +399,7 @@ def main():
                 p_h, v_k = dev.setup_resident(r_h, c.num_instance, trap, g1, g2)
                 set_s = time.perf_counter() - t1
                 w_h = dev.witness_load(c.z)
+                leg_tables = with_tables(dev, p_h, lambda: dev.prove_resident(p_h, r_h, w_h, *rs[0]))
                 dev.prove_resident(p_h, r_h, w_h, *rs[0])
                 k = max(3, min(args.steps, 20))
                 torch.cuda.synchronize()
@@ -388,7 +413,8 @@ def main():
                     gpu_proof_n32 = (pr, pi)
                 legs.append({"workload": d_, "n": n, "ms_per_step": d1 * 1e3, "value": 1.0 / d1, "unit": "proofs/s", "steps": k,
                              "constraints_per_sec": c.num_constraints / d1, "proof_verified": bool(verify(v_k, c.public_inputs, pr, pi)),
-                             "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings()})
+                             "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings(),
+                             "window_tables": leg_tables})
                 for f, h in ((dev.pk_free, p_h), (dev.witness_free, w_h), (dev.r1cs_free, r_h)):
                     f(h)
             except Exception as e:      # noqa: BLE001
@@ -403,7 +429,8 @@ def main():
         alg_bytes = 128.0 * terms_per_launch
         avg_ms = acc["ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        cfg_key = "n%d" % args.matrix_n if args.workload == "matrix" else args.workload
+        tabled = bool(tables_info and (tables_info["window_bits_z"] or tables_info["window_bits_h"]))
+        cfg_key = ("n%d" % args.matrix_n if args.workload == "matrix" else args.workload) + ("_tables" if tabled else "")
         traffic = profile_lookup([cfg_key, "msm_accumulate_g1_traffic_bytes"]) if world == 1 else None
         out = {
             "metric": "groth16_proofs_per_sec", "value": total_proofs / dt, "unit": "proofs/s",
@@ -411,7 +438,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "u32",
             "data": "the reference's circuit on its bench driver's inputs (all-ones matrices, bench/matrix.py:11); real Groth16 key from a seeded trapdoor",
             "proof_verified": bool(verified),
-            "config": {"workload": desc + "; pk/R1CS/assignment resident in HBM; real key (zkg16_setup_resident), last timed proof verified (zkg16_verify)",
+            "config": {"workload": desc + "; pk/R1CS/assignment resident in HBM; real key (zkg16_setup_resident)" +
+                                   (" with window tables (zkg16_pk_precompute)" if tables_info and (tables_info["window_bits_z"] or tables_info["window_bits_h"]) else "") +
+                                   ", last timed proof verified (zkg16_verify)",
                        "parallelism": "1 GPU" if world == 1 else
                                       ("%d GPUs, one proof: %d rank(s) run the witness map and share h_query, z-side index ranges by cost model "
                                        "(zkg16_shard_plan); 1 all_gather(77 words)/proof" % (world, h_ranks) if sharded else
@@ -425,7 +454,7 @@ def main():
                          "terms_per_launch": terms_per_launch,
                          "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (~3,700 "
                                  "v_mad_u64_u32) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command from "
-                                 "profiles/ (bases are re-read once per window); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
+                                 "profiles/ (one 96-byte base or table entry gathered per (scalar, window) term); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
         if plan is not None:
             out["config"]["shard_plan"] = [{"rank": i, "z": [p[0], p[1]], "h": [p[2], p[3]], "blinding": p[4]} for i, p in enumerate(plan)]
@@ -438,10 +467,12 @@ def main():
             n_zero = int(np.all(zz == 0, axis=1).sum())
             nz, nh = zz.shape[0], shp["domain"] - 1
 
-            def nwin(n):
+            def nwin(n, table_bits):
+                if table_bits:
+                    return 254 // table_bits + 1
                 return 254 // (17 if n >= (1 << 23) else 16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
-            z_entries = (nz - n_one - n_zero) * nwin(nz) + n_one
-            h_entries = nh * nwin(nh)
+            z_entries = (nz - n_one - n_zero) * nwin(nz, tables_info["window_bits_z"] if tables_info else 0) + n_one
+            h_entries = nh * nwin(nh, tables_info["window_bits_h"] if tables_info else 0)
             gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
             out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": peak, "unit": "G mixed additions/s",
@@ -450,6 +481,7 @@ def main():
                                   "over-estimate); peak = the same XYZZ mixed addition in a bare register-resident loop at the kernel's "
                                   "occupancy (tools/microbench.hip; profiles/bench_constants_r2.json names the log)"}
         out.update(extra_out)
+        out["window_tables"] = tables_info
         if legs:
             out["legs"] = legs
         if in_flight:

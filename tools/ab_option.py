@@ -36,7 +36,7 @@ for opt, vals in sweeps:
             for _ in range(reps):
                 dev.prove_resident(ph, rh, wh, r, s)
             res[v].append((time.perf_counter() - t0) / reps * 1e3)
-    dev.set_option(opt, 0 if opt != "wm_concurrent" else -1)
+    dev.set_option(opt, 0 if opt not in ("wm_concurrent", "wm_first") else -1)
     for v in vals:
         x = sorted(res[v])
         print("n=%d %s=%d  ms/proof min %.2f median %.2f max %.2f  (proofs identical: %s)" % (n, opt, v, x[0], x[len(x) // 2], x[-1], same), flush=True)

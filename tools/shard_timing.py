@@ -1,6 +1,6 @@
 """Per-rank time of one sharded proof under zkg16_shard_plan's rank roles, measured on ONE GPU that plays every rank in turn
 (development probe; no collective involved: the exchange is one 77-word all_gather, ~0.1 ms):
-   python tools/shard_timing.py [matrix_n] [G,G,...]
+   python tools/shard_timing.py [matrix_n] [G,G,...] [tables]      (tables: every shard gets window tables, zkg16_pk_precompute)
 For each G: the plan the cost model picks (k ranks run the witness map), the plan with k forced to G (round 1's equal split),
 and per rank the time of zkg16_prove_partial.  The slowest rank is the proof's time; speed-up = single-GPU time / that."""
 import os, sys, time
@@ -11,6 +11,7 @@ from zksnark_finalproject_amd import Device
 from zksnark_finalproject_amd.device import shard_plan, z_costs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 Gs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+tables = len(sys.argv) > 3 and sys.argv[3] == "tables"
 dev = Device(0)
 trap, g1, g2 = bench.draw_key_inputs(7)
 c, _, desc = bench.synthesize("matrix", n)
@@ -20,7 +21,7 @@ wh = dev.witness_load(c.z)
 r, s = bench.fr_mont(12345), bench.fr_mont(67890)
 reps = 3 if n >= 100 else 8
 costs = z_costs(c.r1cs, c.z, c.num_instance)
-print(desc, flush=True)
+print(desc + ("  [window tables per shard]" if tables else ""), flush=True)
 single = None
 if 1 not in Gs:
     Gs = [1] + Gs
@@ -36,6 +37,8 @@ for G in Gs:
                 per_rank.append(seen[sig])
                 continue
             sh = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)
+            if tables:
+                dev.pk_precompute(sh)
             dev.prove_partial(sh, rh, wh, r, s)
             t0 = time.perf_counter()
             for _ in range(reps):

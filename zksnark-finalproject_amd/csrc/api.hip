@@ -282,12 +282,18 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // accumulation, with the witness map held back until the first list exists — the accumulation then starts 9 instead of
     // 15 ms into the proof, and the proof takes the same 171-172 ms: kernels that share the device slow each other by about
     // what the overlap saves, the proof is the SUM of its kernels' work.  A high-priority witness-map stream: +1 ms.)
-    if (z_side) {
+    auto enqueue_z_accs = [&]() {
+        if (!z_side) return;
         msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
         msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
         msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
         msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
-    }
+    };
+    // the z-side accumulations either start at once (their kernels and the witness map's then share the device) or wait for the
+    // witness map, which then has the device to itself and lets the h-side sort run underneath the accumulations.  Measured with
+    // window tables: 32x32 12.09 vs 12.41 ms, 46x46 19.9 vs 20.7, 128x128 171.85 vs 170.24 — so only from 2^23 on by default.
+    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : rc.log_n >= 23 ? 1 : 0;
+    if (!wm_first) enqueue_z_accs();
 
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
     // z-side work (measured in one process, n = 32: 18.15 vs 18.58 ms in order; n = 12: 10.05 vs 11.16 ms)
@@ -311,6 +317,10 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         throw;
     }
     if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
+    if (wm_first) {
+        ZK_HIP(hipStreamWaitEvent(ctx->stream, wm_first == 2 ? ev[4] : ev[3], 0));
+        enqueue_z_accs();
+    }
 
     if (z_side) {
         msm_g2_enqueue_reduce(ctx, ctx->slots[0]);
@@ -641,6 +651,16 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_fuse_pointwise = value ? 1 : 0;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "wm_first")) {           // -1 (default): 1 from 2^23 on; 0: z-side accumulations start at once; 1: after the witness map; 2: after the h-side sort too
+        if (value < -1 || value > 2) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_wm_first = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "spmv_dict")) {          // 0 / 1 (default): 16-bit coefficient dictionary in the SpMV; 2: 32-byte coefficients
+        if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_spmv_dict = (int)value;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "reduce_chunk")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return ZKG16_ERR_BAD_ARG;
         ctx->opt_reduce_chunk = (int)value;
@@ -872,9 +892,10 @@ int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, 
 // 20); 46x46 22.6 -> 19.65 at 17 (21.7 at 19); 128x128 181 -> 171.0 at 20 / 22 for z / h (172.0 at 20 / 20, 172.4 at 22 / 22,
 // 176.4 at 19 / 22).  Below 17 bits a bucket run spans more than the four lanes the short fix-up path handles (one resident round
 // of accumulation waves is 2^17 lanes) and everything goes through the long path: 46x46 at 16 bits 27.8 ms, at 15 bits 40 ms.
-// Queries under 2^17 terms get no table by default: there the proof is a chain of latency-bound kernels either way.
+// Queries under 3 * 2^17 terms get no table by default: a 237 k-term shard (46x46 over 4 ranks) measured 10.15 ms with a 17-bit
+// table against 9.33 ms without, the 444 k-term 32x32 key 12.05 against 13.4.
 static int default_table_bits(size_t n) {
-    if (n < ((size_t)1 << 17)) return 0;
+    if (n < ((size_t)3 << 17)) return 0;
     int best = 17;
     double best_cost = 0;
     for (int c : {17, 19, 20, 22}) {
@@ -910,6 +931,15 @@ int zkg16_pk_precompute(zkg16_ctx *ctx, uint64_t pk_handle, int window_bits_z, i
         added += (uint64_t)(254 / ch) * nh * sizeof(G1AffineU);
     }
     if (table_bytes) *table_bytes = added;
+    ZK_API_END(ctx)
+}
+
+int zkg16_pk_table_bits(zkg16_ctx *ctx, uint64_t pk_handle, int *window_bits_z, int *window_bits_h) {
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    if (!pk) return ZKG16_ERR_BAD_HANDLE;
+    if (window_bits_z) *window_bits_z = pk->tab_c_z;
+    if (window_bits_h) *window_bits_h = pk->tab_c_h;
     ZK_API_END(ctx)
 }
 

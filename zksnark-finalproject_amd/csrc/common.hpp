@@ -113,6 +113,16 @@ struct R1csDev {
     int log_n = 0;
     DevBuf rp[3], col[3], cf[3];
     size_t nnz[3] = {0, 0, 0};
+    // coefficient dictionary (poly.hip): R1CS coefficients are a few hundred distinct field elements (215 in the 128x128
+    // MatrixCircuit's 86.6 M non-zeros), so the SpMV reads a 16-bit index per non-zero instead of 32 bytes.  Built on the
+    // device the first time the witness map runs on this handle; dict_state: 0 = not tried, 1 = in use, 2 = too many distinct values
+    DevBuf ci[3], dict;
+    uint32_t ndict = 0;
+    int dict_state = 0;
+    // rows ordered by length, longest first (poly.hip): lane t of the SpMV takes row perm[t], so the 64 rows of a wave have about
+    // the same number of non-zeros.  Built with the dictionary; null = natural order
+    DevBuf perm[3];
+    bool perm_ok = false;
 };
 
 struct WitnessDev { size_t n = 0; DevBuf z; };
@@ -165,6 +175,8 @@ struct zkg16_ctx {
     int opt_min_seg = 0;                              // shortest per-lane run of sorted entries in an accumulation (0 = default)
     int opt_ntt_mode = 1;                             // 1: unsaturated (29-bit limb) butterflies, 0: saturated
     int opt_reduce_mode = 3;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level, 2 = 1 except the proof's last MSM, 3 (default) = 2 from 16-bit windows on
+    int opt_spmv_dict = 0;                            // 0/1: coefficient dictionary in the SpMV (default); 2: plain kernel
+    int opt_wm_first = -1;                            // see zkg16_set_option "wm_first"
     int opt_g1_waves = 0;                             // G1 accumulation waves per SIMD in the one resident round (0 = 2)
     int opt_fixup_aux = 0;                            // 1: fix-up kernels on the MSM's reduction stream
     int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
@@ -205,10 +217,10 @@ struct NttPointwise { const Fr *b, *c; Fr zinv; };
 Fr *ntt_run(zkg16_ctx *ctx, Fr *src, Fr *dst, int log_n, bool inverse, bool coset, const NttPointwise *pw = nullptr);
 NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n);
 
-void spmv_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c);
+void spmv_run(zkg16_ctx *ctx, R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c);
 void pointwise_h_run(zkg16_ctx *ctx, Fr *ab_a, const Fr *b, const Fr *c, const Fr &zinv, size_t n);
 void fr_from_mont_run(zkg16_ctx *ctx, const Fr *in, Fr *out, size_t n);
-void witness_map_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr **h_out);
+void witness_map_run(zkg16_ctx *ctx, R1csDev &m, const Fr *z, Fr **h_out);
 
 // Scalar-vector side of Pippenger (shared by every MSM over the same scalars).
 struct MsmPlan {

@@ -24,6 +24,7 @@ __device__ __forceinline__ void gst_fr(Fr *p, const Fr &v) {
 struct SpmvArgs {
     const uint64_t *rp[3];
     const uint32_t *col[3];
+    const uint32_t *perm[3];      // row order of the lanes (null: natural order)
     const Fr *cf[3];
     Fr *out[3];
     const Fr *z;
@@ -34,9 +35,13 @@ struct SpmvArgs {
 // Poseidon rows: a few tens), so a row per lane keeps all 64 lanes busy.  Rows >= nc are the padding:
 // a[nc + i] = z[i] for i < num_instance (the "input consistency" rows of LibsnarkReduction), else 0.
 __global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
     if (row >= a.n) return;
+    if (row < a.nc && a.perm[m]) {
+        row = a.perm[m][row];
+        if (row >= a.nc) return;                // never: the order is a permutation of the rows (row_perm_build)
+    }
     Fr acc = Fr::zero();
     if (row < a.nc) {
         const uint64_t lo = a.rp[m][row], hi = a.rp[m][row + 1];
@@ -66,21 +71,309 @@ __global__ void __launch_bounds__(256) fr_from_mont_kernel(const Fr *in, Fr *out
     gst_fr(out + i, fp_from_mont(gld_fr(in + i)));
 }
 
-void spmv_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c) {
-    SpmvArgs s;
-    for (int i = 0; i < 3; i++) {
-        s.rp[i] = m.rp[i].as<uint64_t>();
-        s.col[i] = m.col[i].as<uint32_t>();
-        s.cf[i] = m.cf[i].as<Fr>();
+// ------------------------------------------------------------------------------------------------ coefficient dictionary
+// The coefficients of an R1CS are a small set of field elements (1, -1, the Poseidon MDS entries and round constants, small
+// integers).  One pass over the three coefficient arrays puts the distinct values into an open-addressing table (claimed with
+// one compare-and-swap per NEW value), a one-block pass numbers the used slots densely, a third rewrites the slot numbers: from
+// then on the SpMV reads 2 bytes per non-zero and takes the coefficient from LDS.  More than DICT_MAX distinct values: the
+// handle keeps the plain kernel.
+static constexpr uint32_t DICT_CAP = 4096, DICT_MAX = 1024;
+struct DictArgs {
+    const Fr *cf;
+    size_t nnz;
+    uint16_t *idx;
+    uint32_t *keys;          // [DICT_CAP][8]
+    uint32_t *state;         // [DICT_CAP]: 0 free, 1 being written, 2 ready
+    uint32_t *count;         // [0] values inserted, [1] overflow flag, [2] dense count
+};
+// slot of `c` in the global table (inserted if new); 0xffff after an overflow
+__device__ __forceinline__ uint32_t dict_global_slot(const DictArgs &a, const Fr &c, uint32_t h) {
+    uint32_t p = h & (DICT_CAP - 1);
+    // every path through the body ends the lane's turn for this iteration: a lane that finds a slot "being written" simply looks
+    // again on the next trip, so the lane that owns the slot (possibly in the same wave) is never waited for inside a branch
+    for (uint32_t trips = 0; trips < 64u * DICT_CAP; trips++) {
+        if (__hip_atomic_load(a.count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0xffffu;
+        const uint32_t s = __hip_atomic_load(a.state + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (s == 2) {
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 8; k++) same = same && __hip_atomic_load(a.keys + 8 * p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.l[k];
+            if (same) return p;
+            p = (p + 1) & (DICT_CAP - 1);
+        } else if (s == 0) {
+            if (atomicCAS(a.state + p, 0u, 1u) == 0u) {
+                if (atomicAdd(a.count, 1u) >= DICT_MAX) break;
+#pragma unroll
+                for (int k = 0; k < 8; k++) __hip_atomic_store(a.keys + 8 * p + k, c.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.state + p, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return p;
+            }
+        }
     }
-    s.out[0] = a; s.out[1] = b; s.out[2] = c;
-    s.z = z;
-    s.nc = m.num_constraints;
-    s.num_instance = m.num_instance;
-    s.n = (size_t)1 << m.log_n;
-    const unsigned grid = (unsigned)((s.n + 255) / 256);
+    __hip_atomic_store(a.count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // table full (or never settled): give up for this handle
+    return 0xffffu;
+}
+// A workgroup walks DICT_CHUNK consecutive non-zeros and remembers the slots it has looked up in a write-once LDS table (512
+// entries, direct-mapped on other hash bits), so the global table — a few hundred hot addresses for the whole device — is
+// consulted once per distinct value per workgroup instead of once per non-zero.
+static constexpr uint32_t DICT_CHUNK = 16384, DICT_LOCAL = 512;
+__global__ void __launch_bounds__(256) coef_dict_kernel(DictArgs a) {
+    __shared__ uint32_t l_slot[DICT_LOCAL];              // 0 free, 0xffffffff being written, else slot + 1
+    __shared__ uint32_t l_key[DICT_LOCAL * 8];
+    for (uint32_t e = threadIdx.x; e < DICT_LOCAL; e += blockDim.x) l_slot[e] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * DICT_CHUNK;
+    for (uint32_t j = threadIdx.x; j < DICT_CHUNK; j += blockDim.x) {
+        const size_t i = base + j;
+        if (i >= a.nnz) break;
+        const Fr c = gld_fr(a.cf + i);
+        uint32_t h = c.l[0] * 0x9E3779B1u ^ c.l[1] * 0x85EBCA77u ^ c.l[2] * 0xC2B2AE3Du ^ c.l[5] * 0x27D4EB2Fu ^ c.l[7];
+        h ^= h >> 15;
+        const uint32_t lp = (h >> 16) & (DICT_LOCAL - 1);
+        uint32_t found = 0xffffffffu;
+        const uint32_t ls = __hip_atomic_load(l_slot + lp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ls != 0u && ls != 0xffffffffu) {
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 8; k++) same = same && l_key[lp * 8 + k] == c.l[k];
+            if (same) found = ls - 1u;
+        }
+        if (found == 0xffffffffu) {
+            found = dict_global_slot(a, c, h);
+            if (ls == 0u && found != 0xffffu && atomicCAS(l_slot + lp, 0u, 0xffffffffu) == 0u) {      // this lane fills the free local entry
+#pragma unroll
+                for (int k = 0; k < 8; k++) l_key[lp * 8 + k] = c.l[k];
+                __hip_atomic_store(l_slot + lp, found + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        a.idx[i] = (uint16_t)found;
+    }
+}
+// one block: dense numbers for the used slots (slot order), the dense value table, and slot -> dense in state[]
+__global__ void __launch_bounds__(1024) coef_dict_compact_kernel(uint32_t *keys, uint32_t *state, uint32_t *count, Fr *dict) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    constexpr uint32_t PER = DICT_CAP / 1024;
+    uint32_t used[PER], mine = 0;
+    for (uint32_t j = 0; j < PER; j++) {
+        used[j] = state[t * PER + j] == 2u ? 1u : 0u;
+        mine += used[j];
+    }
+    part[t] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t next = part[t] - mine;
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t p = t * PER + j;
+        if (used[j]) {
+            Fr v;
+            for (int k = 0; k < 8; k++) v.l[k] = keys[8 * p + k];
+            if (next < DICT_MAX) gst_fr(dict + next, v);
+            state[p] = next++;
+        }
+    }
+    if (t == 1023) count[2] = part[1023];
+}
+__global__ void __launch_bounds__(256) coef_dict_remap_kernel(uint16_t *idx, size_t nnz, const uint32_t *dense) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) idx[i] = (uint16_t)dense[idx[i] & (DICT_CAP - 1)];
+}
+
+struct SpmvDictArgs {
+    const uint64_t *rp[3];
+    const uint32_t *col[3];
+    const uint32_t *perm[3];
+    const uint16_t *ci[3];
+    Fr *out[3];
+    const Fr *z, *dict;
+    uint32_t ndict;
+    size_t nc, num_instance, n;
+};
+// the same row-per-lane product with the coefficient taken from the dictionary in LDS ([8][ndict] words: neighbouring lanes
+// reading different entries spread over the banks); a coefficient equal to one (40 % of the MatrixCircuit's, all of its C
+// matrix) costs no product
+__global__ void __launch_bounds__(256) spmv_dict_kernel(SpmvDictArgs a) {
+    extern __shared__ uint32_t s_dict[];                 // [8][ndict] limbs, then ndict flag bytes
+    uint8_t *s_one = reinterpret_cast<uint8_t *>(s_dict + 8 * a.ndict);
+    for (uint32_t e = threadIdx.x; e < a.ndict; e += blockDim.x) {
+        const Fr v = gld_fr(a.dict + e);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_dict[k * a.ndict + e] = v.l[k];
+        s_one[e] = v == Fr::one() ? 1 : 0;
+    }
+    __syncthreads();
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (row >= a.n) return;
+    if (row < a.nc && a.perm[m]) {
+        row = a.perm[m][row];
+        if (row >= a.nc) return;                // never: the order is a permutation of the rows (row_perm_build)
+    }
+    Fr acc = Fr::zero();
+    if (row < a.nc) {
+        const uint64_t lo = a.rp[m][row], hi = a.rp[m][row + 1];
+        for (uint64_t k = lo; k < hi; k++) {
+            const uint32_t e = a.ci[m][k];
+            const Fr v = gld_fr(a.z + a.col[m][k]);
+            if (s_one[e]) {
+                acc = fp_add(acc, v);
+            } else {
+                Fr c;
+#pragma unroll
+                for (int q = 0; q < 8; q++) c.l[q] = s_dict[q * a.ndict + e];
+                acc = fp_add(acc, fp_mul(c, v));
+            }
+        }
+    } else if (m == 0 && row < a.nc + a.num_instance) {
+        acc = gld_fr(a.z + (row - a.nc));
+    }
+    gst_fr(a.out[m] + row, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ rows by length
+// The reference's matrices mix rows of 1 non-zero (88 % of them) with rows of 4 .. 133 (the Poseidon rounds' linear layers), in
+// runs of every length: with a row per lane in natural order a wave runs as long as its longest row while most lanes idle —
+// the SpMV of the 128x128 circuit took 6.3 ms, 4 of them the multiplier at ~8 % lane utilisation.  The rows are therefore
+// ordered by length class (min(length, 255), longest first) once per handle: a counting sort with per-workgroup LDS histograms.
+// The order inside a class does not matter (every row is computed on its own), so it is left to the atomics.
+__global__ void __launch_bounds__(256) row_len_hist_kernel(const uint64_t *rp, size_t nc, uint32_t *hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < nc) {
+        const uint64_t len = rp[row + 1] - rp[row];
+        atomicAdd(&h[len > 255 ? 255u : (uint32_t)len], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
+}
+// cursor[c] = first position of class c in the order (classes laid out longest first); advanced by each workgroup's share
+__global__ void __launch_bounds__(256) row_perm_kernel(const uint64_t *rp, size_t nc, uint32_t *cursor, uint32_t *perm) {
+    __shared__ uint32_t h[256], base[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = 0, mine = 0;
+    if (row < nc) {
+        const uint64_t len = rp[row + 1] - rp[row];
+        cls = len > 255 ? 255u : (uint32_t)len;
+        mine = atomicAdd(&h[cls], 1u);
+    }
+    __syncthreads();
+    base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(cursor + threadIdx.x, h[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (row < nc) {
+        const uint32_t pos = base[cls] + mine;
+        if (pos < nc) perm[pos] = (uint32_t)row;             // always true when the histogram was of these row pointers
+    }
+}
+static void row_perm_build(zkg16_ctx *ctx, R1csDev &m) {
+    const size_t nc = m.num_constraints;
+    if (nc < 4096 || nc >= ((size_t)1 << 32)) return;
+    DevBuf hist(3 * 256 * sizeof(uint32_t));
+    ZK_HIP(hipMemsetAsync(hist.p, 0, 3 * 256 * sizeof(uint32_t), ctx->stream));
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL(row_len_hist_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, hist.as<uint32_t>() + 256 * i);
+    ZK_HIP(hipGetLastError());
+    uint32_t h[3 * 256];
+    ZK_HIP(hipMemcpyAsync(h, hist.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; i++) {
+        uint64_t run = 0;
+        for (int c = 255; c >= 0; c--) {                      // longest class first
+            const uint32_t cnt = h[256 * i + c];
+            h[256 * i + c] = (uint32_t)run;
+            run += cnt;
+        }
+        if (run != nc) return;                                // cannot happen; the natural order stays in use
+    }
+    ZK_HIP(hipMemcpyAsync(hist.p, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < 3; i++) {
+        m.perm[i].ensure(nc * sizeof(uint32_t));
+        hipLaunchKernelGGL(row_perm_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, hist.as<uint32_t>() + 256 * i,
+                           m.perm[i].as<uint32_t>());
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));               // `h` and `hist` go out of scope
+    m.perm_ok = true;
+}
+
+static void coef_dict_build(zkg16_ctx *ctx, R1csDev &m) {
+    m.dict_state = 2;
+    row_perm_build(ctx, m);
+    const size_t total = m.nnz[0] + m.nnz[1] + m.nnz[2];
+    if (total < 4096) return;        // tiny systems: not worth three launches and a sync
+    DevBuf scratch((DICT_CAP * 9 + 4) * sizeof(uint32_t));
+    uint32_t *keys = scratch.as<uint32_t>(), *state = keys + 8 * DICT_CAP, *count = state + DICT_CAP;
+    ZK_HIP(hipMemsetAsync(scratch.p, 0, (DICT_CAP * 9 + 4) * sizeof(uint32_t), ctx->stream));
+    m.dict.ensure(DICT_MAX * sizeof(Fr));
+    for (int i = 0; i < 3; i++) {
+        m.ci[i].ensure((m.nnz[i] ? m.nnz[i] : 1) * sizeof(uint16_t));
+        if (!m.nnz[i]) continue;
+        const DictArgs d{m.cf[i].as<Fr>(), m.nnz[i], m.ci[i].as<uint16_t>(), keys, state, count};
+        hipLaunchKernelGGL(coef_dict_kernel, dim3((unsigned)((m.nnz[i] + DICT_CHUNK - 1) / DICT_CHUNK)), dim3(256), 0, ctx->stream, d);
+    }
+    hipLaunchKernelGGL(coef_dict_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, keys, state, count, m.dict.as<Fr>());
+    for (int i = 0; i < 3; i++)
+        if (m.nnz[i])
+            hipLaunchKernelGGL(coef_dict_remap_kernel, dim3((unsigned)((m.nnz[i] + 255) / 256)), dim3(256), 0, ctx->stream, m.ci[i].as<uint16_t>(),
+                               m.nnz[i], state);
+    ZK_HIP(hipGetLastError());
+    uint32_t res[3] = {0, 0, 0};
+    ZK_HIP(hipMemcpyAsync(res, count, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (res[1] || res[2] == 0 || res[2] > DICT_MAX) {            // too many distinct values: this handle keeps the plain kernel
+        for (int i = 0; i < 3; i++) m.ci[i].release();
+        m.dict.release();
+        return;
+    }
+    m.ndict = res[2];
+    m.dict_state = 1;
+}
+
+void spmv_run(zkg16_ctx *ctx, R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c) {
+    if (m.dict_state == 0 && ctx->opt_spmv_dict != 2) coef_dict_build(ctx, m);
+    const size_t n = (size_t)1 << m.log_n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
     ScopedKernelTimer kt(ctx, "spmv_kernel", (double)(m.nnz[0] + m.nnz[1] + m.nnz[2]));
-    hipLaunchKernelGGL(spmv_kernel, dim3(grid, 3), dim3(256), 0, ctx->stream, s);
+    if (m.dict_state == 1 && ctx->opt_spmv_dict != 2) {
+        SpmvDictArgs s;
+        for (int i = 0; i < 3; i++) {
+            s.rp[i] = m.rp[i].as<uint64_t>();
+            s.col[i] = m.col[i].as<uint32_t>();
+            s.ci[i] = m.ci[i].as<uint16_t>();
+            s.perm[i] = m.perm_ok ? m.perm[i].as<uint32_t>() : nullptr;
+        }
+        s.out[0] = a; s.out[1] = b; s.out[2] = c;
+        s.z = z;
+        s.dict = m.dict.as<Fr>();
+        s.ndict = m.ndict;
+        s.nc = m.num_constraints;
+        s.num_instance = m.num_instance;
+        s.n = n;
+        hipLaunchKernelGGL(spmv_dict_kernel, dim3(grid, 3), dim3(256), m.ndict * 33 + 16, ctx->stream, s);
+    } else {
+        SpmvArgs s;
+        for (int i = 0; i < 3; i++) {
+            s.rp[i] = m.rp[i].as<uint64_t>();
+            s.col[i] = m.col[i].as<uint32_t>();
+            s.cf[i] = m.cf[i].as<Fr>();
+            s.perm[i] = (m.perm_ok && ctx->opt_spmv_dict != 2) ? m.perm[i].as<uint32_t>() : nullptr;
+        }
+        s.out[0] = a; s.out[1] = b; s.out[2] = c;
+        s.z = z;
+        s.nc = m.num_constraints;
+        s.num_instance = m.num_instance;
+        s.n = n;
+        hipLaunchKernelGGL(spmv_kernel, dim3(grid, 3), dim3(256), 0, ctx->stream, s);
+    }
     ZK_HIP(hipGetLastError());
 }
 
@@ -101,7 +394,7 @@ void fr_from_mont_run(zkg16_ctx *ctx, const Fr *in, Fr *out, size_t n) {
 // The transforms ping-pong between each vector and the one scratch buffer (ifft: x -> tmp, coset fft: tmp -> x), and the
 // point-wise (ab - c)/Z rides on the load of the seventh transform: no device-to-device copy and no separate point-wise
 // pass (round 1 had both: 8 extra passes over N x 32 B per proof).  Result pointer = ctx->poly[3].
-void witness_map_run(zkg16_ctx *ctx, const R1csDev &m, const Fr *z, Fr **h_out) {
+void witness_map_run(zkg16_ctx *ctx, R1csDev &m, const Fr *z, Fr **h_out) {
     const size_t n = (size_t)1 << m.log_n;
     for (int i = 0; i < 4; i++) ctx->poly[i].ensure(n * sizeof(Fr));
     Fr *a = ctx->poly[0].as<Fr>(), *b = ctx->poly[1].as<Fr>(), *c = ctx->poly[2].as<Fr>(), *tmp = ctx->poly[3].as<Fr>();

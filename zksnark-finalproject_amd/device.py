@@ -78,6 +78,12 @@ class Device:
         self._check(self.lib.zkg16_pk_precompute(self.ctx, pk_h, int(window_bits_z), int(window_bits_h), C.byref(added)))
         return added.value
 
+    def pk_table_bits(self, pk_h):
+        """-> (window bits of the z-side tables, of the h-side table); 0 = none (zkg16_pk_table_bits)."""
+        bz, bh = C.c_int(0), C.c_int(0)
+        self._check(self.lib.zkg16_pk_table_bits(self.ctx, pk_h, C.byref(bz), C.byref(bh)))
+        return bz.value, bh.value
+
     def pk_slice(self, pk_h, z_lo, z_hi, h_lo, h_hi, blinding):
         """A shard cut out of a whole resident key, device to device (zkg16_pk_slice)."""
         handle = C.c_uint64()
