@@ -141,7 +141,32 @@ def test_segmented_threaded_build_equals_in_order_build(n, monkeypatch):
     assert np.array_equal(fast.z, plain.z)
 
 
-@pytest.mark.parametrize("n", [2, 5, 12])
+@pytest.mark.parametrize("n,chunks", [(16, 2), (17, 4), (23, 3), (24, 4), (24, 16), (34, 4), (35, 1)])
+def test_chunked_sponges_equal_in_order_build(n, chunks, monkeypatch):
+    """From 128 permutations on, every Poseidon sponge of the MatrixCircuit is built as chunks of permutations on their own
+    threads: a chunk gets the native state in front of the permutation before its first one and replays that permutation on a
+    scratch circuit to obtain its entering state (csrc/circuits.hip, plan_sponge_chunks).  Same CSR arrays, same assignment and
+    the same hashes as the in-order build; odd n: the last permutation absorbs one element; from n = 32 on matrix_mul is built as
+    three segments of product rows as well."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    rng = np.random.default_rng(900 + n)
+    a = rng.integers(0, 1 << 40, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 40, size=(n, n), dtype=np.uint64)
+    monkeypatch.setenv("ZKG16_SYNTH_CHUNKS", str(chunks))
+    monkeypatch.setenv("ZKG16_SYNTH_STRICT", "1")        # no silent fall-back to the in-order build
+    fast = matrix_circuit(a, b)
+    monkeypatch.setenv("ZKG16_SYNTH_THREADS", "0")
+    plain = matrix_circuit(a, b)
+    assert fast.num_constraints == plain.num_constraints and fast.num_vars == plain.num_vars
+    for m in ("a", "b", "c"):
+        for x, y in zip(fast.r1cs[m], plain.r1cs[m]):
+            assert np.array_equal(x, y), m
+    assert np.array_equal(fast.z, plain.z)
+    assert np.array_equal(fast.public_inputs, plain.public_inputs)
+    assert fast.satisfied in (True, None) and plain.satisfied in (True, None)      # None: not evaluated above 200,000 constraints
+
+
+@pytest.mark.parametrize("n", [2, 5, 12, 33])
 def test_assignment_only_build_equals_full_synthesis(n):
     """zkg16_circuit_matrix_witness (term bookkeeping off in every builder thread) gives exactly the assignment of the full
     synthesis; a wrong variable count is rejected."""

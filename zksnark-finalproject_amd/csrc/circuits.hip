@@ -398,6 +398,90 @@ Lc poseidon_hash_gadget(Circuit &cs, const std::vector<Lc> &elems) {
     return st[POSEIDON_CAP];
 }
 
+// ---- one sponge over several segments.  Permutation p absorbs elements [RATE p, RATE p + RATE) and allocates 265 witnesses
+// (the first one 260), so the witness offset of every permutation is known up front, and the state a permutation leaves is a
+// fixed linear form over ITS OWN last three S-box witnesses whatever went in.  A chunk that starts at permutation p_lo >= 2
+// therefore needs only the native state values in front of permutation p_lo - 1: it replays that one permutation on a
+// scratch circuit (numbered where the real one is) to obtain the entering state as FpVars, then continues exactly as the
+// sequential gadget would.  Chunks of one hash run on their own threads (build_matrix_circuit).
+static constexpr size_t PERM_WITNESSES = 265;
+struct SpongeChunk { Circuit *seg; size_t p_lo, p_hi; Fr pre[3]; };
+template <class AddSegment>
+static std::vector<SpongeChunk> plan_sponge_chunks(AddSegment &&add_segment, size_t wit_base, size_t count, size_t want) {
+    const size_t perms = (count + POSEIDON_RATE - 1) / POSEIDON_RATE;
+    size_t k = want;
+    while (k > 1 && perms / k < 64) k--;
+    std::vector<SpongeChunk> ch(k);
+    for (size_t j = 0; j < k; j++) {
+        ch[j].p_lo = j == 0 ? 0 : std::max<size_t>(2, perms * j / k);
+        ch[j].p_hi = j + 1 == k ? perms : std::max<size_t>(2, perms * (j + 1) / k);
+        ch[j].seg = &add_segment(wit_base + (ch[j].p_lo == 0 ? 0 : ch[j].p_lo * PERM_WITNESSES - 5));
+        for (int i = 0; i < 3; i++) ch[j].pre[i] = Fr::zero();
+    }
+    return ch;
+}
+// the native sponge, recording for every chunk after the first the state in front of permutation p_lo - 1; returns the hash
+static Fr poseidon_native_with_cuts(const Fr *elems, size_t count, std::vector<SpongeChunk> &ch) {
+    Fr st[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    const size_t perms = (count + POSEIDON_RATE - 1) / POSEIDON_RATE;
+    size_t next = 1;
+    for (size_t p = 0; p < perms; p++) {
+        for (size_t pos = 0; pos < POSEIDON_RATE && p * POSEIDON_RATE + pos < count; pos++)
+            st[POSEIDON_CAP + pos] = fp_add(st[POSEIDON_CAP + pos], elems[p * POSEIDON_RATE + pos]);
+        if (next < ch.size() && ch[next].p_lo == p + 1) {
+            for (int i = 0; i < 3; i++) ch[next].pre[i] = st[i];
+            next++;
+        }
+        permute_native(st);
+    }
+    return st[POSEIDON_CAP];
+}
+static Lc poseidon_hash_chunk(const SpongeChunk &ck, const std::vector<Lc> &elems) {
+    Circuit &cs = *ck.seg;
+    PermTemplates tpls;
+    const char *env = getenv("ZKG16_SYNTH_GENERIC");
+    tpls.enabled = !(env && env[0] == '1');
+    Lc st[3];
+    if (ck.p_lo == 0) {
+        for (int i = 0; i < 3; i++) st[i] = cs.constant(Fr::zero());
+    } else {
+        Circuit scratch;
+        scratch.wit_base = cs.wit_base - PERM_WITNESSES;        // where permutation p_lo - 1 numbers its witnesses
+        for (int i = 0; i < 3; i++) {
+            st[i].t.assign(1, Term{WIT | (VarId)0, Fr::one()});   // any non-constant form: the state that comes out does not depend on it
+            st[i].val = ck.pre[i];
+            st[i].is_const = false;
+        }
+        permute_gadget_generic(scratch, st);
+        if (scratch.witness.size() != PERM_WITNESSES) throw std::logic_error("sponge chunk: witness count of a permutation");
+        for (int i = 0; i < 3; i++)
+            for (const Term &x : st[i].t)
+                if (!(x.v & WIT) || (x.v & ~WIT) < scratch.wit_base) throw std::logic_error("sponge chunk: leaving state refers to its input");
+    }
+    for (size_t p = ck.p_lo; p < ck.p_hi; p++) {
+        for (size_t pos = 0; pos < POSEIDON_RATE && p * POSEIDON_RATE + pos < elems.size(); pos++)
+            st[POSEIDON_CAP + pos] = Circuit::add(st[POSEIDON_CAP + pos], elems[p * POSEIDON_RATE + pos]);
+        permute_gadget(cs, tpls, st);
+    }
+    return st[POSEIDON_CAP];
+}
+// all chunks of one hash: the native pass first (it also yields the hash value), then chunk 0 here and the others on threads
+static Lc poseidon_hash_chunked(std::vector<SpongeChunk> &ch, const std::vector<Lc> &elems, const Fr *vals, Fr &hash_out) {
+    hash_out = poseidon_native_with_cuts(vals, elems.size(), ch);
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(ch.size());
+    std::vector<Lc> res(ch.size());
+    auto run = [&](size_t j) {
+        try { res[j] = poseidon_hash_chunk(ch[j], elems); } catch (...) { err[j] = std::current_exception(); g_terms = true; }
+    };
+    for (size_t j = 1; j < ch.size(); j++) th.emplace_back(run, j);
+    run(0);
+    for (auto &t : th) t.join();
+    for (const std::exception_ptr &e : err)
+        if (e) std::rethrow_exception(e);
+    return res.back();
+}
+
 #include "prime_circuit.inc"
 
 }  // namespace
@@ -531,23 +615,54 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     Fr hash_a, hash_b, hash_c;
     Lc ha, hb, hc;
     const size_t hw = threaded ? poseidon_hash_witnesses(nn) : 0;
-    Circuit &seg_a = c->add_segment(2 * nn);
-    Circuit &seg_b = c->add_segment(2 * nn + hw);
+    // every hash is cut into chunks of permutations with a thread each (plan_sponge_chunks): 3 x 4 + the matrix_mul thread fit
+    // the 16 host cores a GPU comes with; in-order building keeps one segment per hash
+    size_t chunks = 1;
+    if (threaded) {
+        const char *ce = getenv("ZKG16_SYNTH_CHUNKS");
+        chunks = ce ? (size_t)atoi(ce) : 4;
+        if (chunks < 1 || chunks > 16) chunks = 1;
+    }
+    auto add_seg = [c](size_t base) -> Circuit & { return c->add_segment(base); };
+    std::vector<SpongeChunk> ch_a = plan_sponge_chunks(add_seg, 2 * nn, nn, chunks);
+    std::vector<SpongeChunk> ch_b = plan_sponge_chunks(add_seg, 2 * nn + hw, nn, chunks);
+    Circuit &seg_a = *ch_a[0].seg, &seg_b = *ch_b[0].seg;
     Circuit &seg_mid = c->add_segment(0);
-    Circuit &seg_c = c->add_segment(2 * nn + 2 * hw);           // matrix_mul
-    Circuit &seg_d = c->add_segment(2 * nn + 2 * hw + nn + nn * (n + 1));      // hash of the product: starts after matrix_mul's witnesses
+    // matrix_mul: rows [n t / parts, n (t + 1) / parts) of the product per segment (each (i, j) allocates 1 + n witnesses)
+    const size_t mm_parts = (threaded && n >= 32) ? 3 : 1;
+    std::vector<Circuit *> seg_mm;
+    for (size_t t = 0; t < mm_parts; t++)
+        seg_mm.push_back(&c->add_segment(2 * nn + 2 * hw + (t == 0 ? 0 : nn + (n * t / mm_parts) * n * (n + 1))));
+    Circuit &seg_c = *seg_mm[0];
+    std::vector<SpongeChunk> ch_d = plan_sponge_chunks(add_seg, 2 * nn + 2 * hw + nn + nn * (n + 1), nn, chunks);      // hash of the product: starts after matrix_mul's witnesses
+    Circuit &seg_d = *ch_d[0].seg;
     Circuit &seg_tail = c->add_segment(0);
     std::exception_ptr err_a, err_b, err_c, err_d;
+    const bool synth_trace = getenv("ZKG16_SYNTH_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (synth_trace) fprintf(stderr, "synthesis: %s done at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    };
     auto build_a = [&]() {
         try {
-            hash_a = poseidon_hash_native(av.data(), nn);
-            ha = poseidon_hash_gadget(seg_a, ma);
+            if (ch_a.size() > 1) {
+                ha = poseidon_hash_chunked(ch_a, ma, av.data(), hash_a);
+            } else {
+                hash_a = poseidon_hash_native(av.data(), nn);
+                ha = poseidon_hash_gadget(seg_a, ma);
+            }
+            lap("hash_a");
         } catch (...) { err_a = std::current_exception(); g_terms = true; }
     };
     auto build_b = [&]() {
         try {
-            hash_b = poseidon_hash_native(bv.data(), nn);
-            hb = poseidon_hash_gadget(seg_b, mb);
+            if (ch_b.size() > 1) {
+                hb = poseidon_hash_chunked(ch_b, mb, bv.data(), hash_b);
+            } else {
+                hash_b = poseidon_hash_native(bv.data(), nn);
+                hb = poseidon_hash_gadget(seg_b, mb);
+            }
+            lap("hash_b");
         } catch (...) { err_b = std::current_exception(); g_terms = true; }
     };
     // hash of C: entry (i, j) of the product is the symbolic sum  sum_ij + sum_k product_ijk  (constraints.rs:87-92), whose
@@ -555,7 +670,6 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
     // linear combinations can be written down without waiting for matrix_mul to run
     auto build_d = [&]() {
         try {
-            hash_c = poseidon_hash_native(cv.data(), nn);
             std::vector<Lc> mc(nn);
             const Fr one = Fr::one();
             for (size_t e = 0; e < nn; e++) {
@@ -565,7 +679,13 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
                 mc[e].val = cv[e];
                 mc[e].is_const = false;
             }
-            hc = poseidon_hash_gadget(seg_d, mc);
+            if (ch_d.size() > 1) {
+                hc = poseidon_hash_chunked(ch_d, mc, cv.data(), hash_c);
+            } else {
+                hash_c = poseidon_hash_native(cv.data(), nn);
+                hc = poseidon_hash_gadget(seg_d, mc);
+            }
+            lap("hash_c");
         } catch (...) { err_d = std::current_exception(); g_terms = true; }
     };
     // the inputs come first in arkworks' order, but their values (the native hashes) are only needed at the end: the
@@ -585,24 +705,44 @@ static void build_matrix_circuit(zkg16_circuit *c, size_t n, const uint64_t *a, 
         seg_c.wit_base = seg_b.next_wit();
         seg_d.wit_base = seg_c.wit_base + nn + nn * (n + 1);
     }
-    // matrix_mul (constraints.rs:78-99), on this thread
-    try {
-        for (size_t i = 0; i < nn; i++) seg_c.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
-        for (size_t i = 0; i < n; i++)
-            for (size_t j = 0; j < n; j++) {
-                seg_c.new_witness(Fr::zero());                  // the sum's seed (:87); the running sum itself is symbolic
-                for (size_t k = 0; k < n; k++) {
-                    const Lc &ij = ma[i * n + k], &jk = mb[k * n + j];
-                    Lc product = seg_c.mul(ij, jk);            // `*`: product witness + constraint (:91)
-                    seg_c.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
+    // matrix_mul (constraints.rs:78-99): part 0 on this thread, the others on their own
+    std::vector<std::exception_ptr> err_mm(mm_parts);
+    auto build_mm = [&](size_t t) {
+        try {
+            Circuit &sg = *seg_mm[t];
+            if (t == 0)
+                for (size_t i = 0; i < nn; i++) sg.new_witness(Fr::zero());     // pre-allocated, never constrained (:84)
+            for (size_t i = n * t / mm_parts; i < n * (t + 1) / mm_parts; i++)
+                for (size_t j = 0; j < n; j++) {
+                    sg.new_witness(Fr::zero());                  // the sum's seed (:87); the running sum itself is symbolic
+                    for (size_t k = 0; k < n; k++) {
+                        const Lc &ij = ma[i * n + k], &jk = mb[k * n + j];
+                        Lc product = sg.mul(ij, jk);            // `*`: product witness + constraint (:91)
+                        sg.mul_equals(ij, jk, product);         // second constraint on the same triple (:93)
+                    }
                 }
-            }
-    } catch (...) { err_c = std::current_exception(); g_terms = true; }
+        } catch (...) { err_mm[t] = std::current_exception(); g_terms = true; }
+    };
+    std::vector<std::thread> tmm;
+    for (size_t t = 1; t < mm_parts; t++) tmm.emplace_back(build_mm, t);
+    build_mm(0);
+    for (auto &t : tmm) t.join();
+    lap("matrix_mul");
+    for (const std::exception_ptr &e : err_mm)
+        if (e && !err_c) err_c = e;
     if (threaded) { ta.join(); tb.join(); td.join(); }
     else build_d();
     for (const std::exception_ptr &e : {err_a, err_b, err_c, err_d})
         if (e) std::rethrow_exception(e);
-    if (seg_b.wit_base != seg_a.next_wit() || seg_c.wit_base != seg_b.next_wit() || seg_d.wit_base != seg_c.next_wit()) throw std::logic_error("matrix circuit: segment offsets do not line up");
+    {       // every witness-allocating segment must start where the one before it ended
+        std::vector<const Circuit *> order;
+        for (const SpongeChunk &k : ch_a) order.push_back(k.seg);
+        for (const SpongeChunk &k : ch_b) order.push_back(k.seg);
+        for (const Circuit *sg : seg_mm) order.push_back(sg);
+        for (const SpongeChunk &k : ch_d) order.push_back(k.seg);
+        for (size_t i = 0; i + 1 < order.size(); i++)
+            if (order[i + 1]->wit_base != order[i]->next_wit()) throw std::logic_error("matrix circuit: segment offsets do not line up");
+    }
     head.instance[1] = hash_a;
     head.instance[2] = hash_b;
     in_a.val = hash_a;
@@ -632,6 +772,7 @@ int zkg16_circuit_matrix(size_t n, const uint64_t *a, const uint64_t *b, zkg16_c
             g_terms = true;
             delete c;
             if (!threaded) return ZKG16_ERR_UNSUPPORTED;      // a template replay that did not line up: a bug, never a property of the input
+            if (getenv("ZKG16_SYNTH_STRICT")) return ZKG16_ERR_UNSUPPORTED;      // tests: the concurrent build itself must succeed
             threaded = false;                                  // predicted segment offsets were off: build in order instead
         }
     }
@@ -704,17 +845,25 @@ int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b,
         if (threaded) { ta = std::thread(do_a); tb = std::thread(do_b); } else { do_a(); do_b(); }
         // matrix_mul: the pre-allocated entries and the sums' seeds are zero, the products are a_ik * b_kj in allocation order
         for (size_t i = 0; i < nn; i++) Z[off_mc + i] = Fr::zero();
-        for (size_t i = 0; i < n; i++)
-            for (size_t j = 0; j < n; j++) {
-                Fr *blk = Z + off_mm + (i * n + j) * (n + 1);
-                blk[0] = Fr::zero();
-                Fr sum = Fr::zero();
-                for (size_t k = 0; k < n; k++) {
-                    blk[1 + k] = fp_mul(av[i * n + k], bv[k * n + j]);
-                    sum = fp_add(sum, blk[1 + k]);
+        // the products sit on the critical path in front of the (sequential) sponge over C: rows of the product in parallel
+        auto rows = [&](size_t i_lo, size_t i_hi) {
+            for (size_t i = i_lo; i < i_hi; i++)
+                for (size_t j = 0; j < n; j++) {
+                    Fr *blk = Z + off_mm + (i * n + j) * (n + 1);
+                    blk[0] = Fr::zero();
+                    Fr sum = Fr::zero();
+                    for (size_t k = 0; k < n; k++) {
+                        blk[1 + k] = fp_mul(av[i * n + k], bv[k * n + j]);
+                        sum = fp_add(sum, blk[1 + k]);
+                    }
+                    cv[i * n + j] = sum;
                 }
-                cv[i * n + j] = sum;
-            }
+        };
+        const size_t helpers = (threaded && n >= 32) ? 5 : 0;
+        std::vector<std::thread> mm;
+        for (size_t t = 0; t < helpers; t++) mm.emplace_back(rows, n * t / (helpers + 1), n * (t + 1) / (helpers + 1));
+        rows(n * helpers / (helpers + 1), n);
+        for (auto &t : mm) t.join();
         hc = poseidon_hash_witness_values(cv.data(), nn, Z + off_hc, nc);
         if (threaded) { ta.join(); tb.join(); }
         if (na != hw || nb != hw || nc != hw) return ZKG16_ERR_UNSUPPORTED;      // the closed form of the sponge's witness count is off: a bug
