@@ -6,6 +6,7 @@
 // There is NO CPU fallback: without a HIP device zkg16_init fails with ZKG16_ERR_NO_DEVICE.
 #include <chrono>
 #include <functional>
+#include <thread>
 
 #include "common.hpp"
 
@@ -292,7 +293,8 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // the z-side accumulations either start at once (their kernels and the witness map's then share the device) or wait for the
     // witness map, which then has the device to itself and lets the h-side sort run underneath the accumulations.  Measured with
     // window tables: 32x32 12.09 vs 12.41 ms, 46x46 19.9 vs 20.7, 128x128 171.85 vs 170.24 — so only from 2^23 on by default.
-    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : rc.log_n >= 23 ? 1 : 0;
+    // (not when the matrices are still being uploaded on the witness map's stream: the accumulations are what hides that)
+    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : (rc.log_n >= 23 && !before_witness_map) ? 1 : 0;
     if (!wm_first) enqueue_z_accs();
 
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
@@ -436,11 +438,24 @@ int r1cs_create(const uint64_t *const rp[3], const uint32_t *const col[3], const
         const size_t nnz = rp[i][num_constraints];
         // row pointers: start at 0, never decrease, end at nnz — spmv_kernel walks [rp[row], rp[row+1]) unchecked on the device
         if (rp[i][0] != 0) return ZKG16_ERR_BAD_ARG;
-        for (size_t row = 0; row < num_constraints; row++)
-            if (rp[i][row] > rp[i][row + 1]) return ZKG16_ERR_BAD_ARG;
-        uint32_t top = 0;
-        for (size_t k = 0; k < nnz; k++) top = col[i][k] > top ? col[i][k] : top;
-        if (nnz && top >= num_variables) return ZKG16_ERR_BAD_ARG;
+        // both scans in slices on a few host threads (86.6 M column indices in the 128x128 circuit: ~0.1 s on one)
+        const int T = (nnz + num_constraints) >= ((size_t)1 << 22) ? 8 : 1;
+        std::vector<int> bad(T, 0);
+        auto scan = [&](int t) {
+            const size_t r0 = num_constraints * t / T, r1 = num_constraints * (t + 1) / T;
+            for (size_t row = r0; row < r1; row++)
+                if (rp[i][row] > rp[i][row + 1]) { bad[t] = 1; return; }
+            const size_t k0 = nnz * t / T, k1 = nnz * (t + 1) / T;
+            uint32_t top = 0;
+            for (size_t k = k0; k < k1; k++) top = col[i][k] > top ? col[i][k] : top;
+            if (k1 > k0 && top >= num_variables) bad[t] = 1;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++)
+            if (bad[t]) return ZKG16_ERR_BAD_ARG;
         r->nnz[i] = nnz;
         r->rp[i].alloc((num_constraints + 1) * sizeof(uint64_t));
         r->col[i].alloc(nnz * sizeof(uint32_t));
@@ -449,13 +464,47 @@ int r1cs_create(const uint64_t *const rp[3], const uint32_t *const col[3], const
     out = std::move(r);
     return ZKG16_OK;
 }
-// host -> device copies of the three matrices, queued on ctx->stream (pageable source: the call itself may take a while)
+// Host -> device copy of a large pageable buffer, queued on ctx->stream.  hipMemcpyAsync from pageable memory goes through
+// the runtime's own single-threaded staging (~9 GB/s measured: the 3.5 GB of a 128x128 R1CS took 0.38 s of the 0.55 s
+// host-pointer proof); here four host threads fill one half of a pinned ring while the DMA engine drains the other.
+static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
+void upload_h2d(zkg16_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes < ((size_t)8 << 20)) {
+        ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return;
+    }
+    for (int i = 0; i < 2; i++)
+        if (!ctx->stage_host[i]) {
+            ZK_HIP(hipHostMalloc(&ctx->stage_host[i], STAGE_BYTES, hipHostMallocDefault));
+            ZK_HIP(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        }
+    const unsigned char *s = static_cast<const unsigned char *>(src);
+    unsigned char *d = static_cast<unsigned char *>(dst);
+    int slot = 0;
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES, slot ^= 1) {
+        const size_t len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+        ZK_HIP(hipEventSynchronize(ctx->stage_done[slot]));         // the copy that last used this half has left it (a fresh event is complete)
+        unsigned char *stage = static_cast<unsigned char *>(ctx->stage_host[slot]);
+        constexpr int T = 4;
+        std::thread th[T - 1];
+        const size_t part = (len / T + 4095) & ~(size_t)4095;
+        for (int t = 1; t < T; t++) {
+            const size_t lo = part * t < len ? part * t : len, hi = part * (t + 1) < len ? part * (t + 1) : len;
+            th[t - 1] = std::thread([=]() { if (hi > lo) memcpy(stage + lo, s + off + lo, hi - lo); });
+        }
+        memcpy(stage, s + off, part < len ? part : len);
+        for (auto &x : th) x.join();
+        ZK_HIP(hipMemcpyAsync(d + off, stage, len, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipEventRecord(ctx->stage_done[slot], ctx->stream));
+    }
+}
+// host -> device copies of the three matrices, queued on ctx->stream (the call returns when the last piece is staged)
 void r1cs_copy(zkg16_ctx *ctx, R1csDev &r, const uint64_t *const rp[3], const uint32_t *const col[3], const uint64_t *const cf[3]) {
     for (int i = 0; i < 3; i++) {
-        ZK_HIP(hipMemcpyAsync(r.rp[i].p, rp[i], (r.num_constraints + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        upload_h2d(ctx, r.rp[i].p, rp[i], (r.num_constraints + 1) * sizeof(uint64_t));
         if (r.nnz[i]) {
-            ZK_HIP(hipMemcpyAsync(r.col[i].p, col[i], r.nnz[i] * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            ZK_HIP(hipMemcpyAsync(r.cf[i].p, cf[i], r.nnz[i] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            upload_h2d(ctx, r.col[i].p, col[i], r.nnz[i] * sizeof(uint32_t));
+            upload_h2d(ctx, r.cf[i].p, cf[i], r.nnz[i] * sizeof(Fr));
         }
     }
 }
@@ -557,6 +606,10 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->wm_stream);
     if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage_host[i]) (void)hipHostFree(ctx->stage_host[i]);
+        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    }
     for (auto &sl : ctx->slots) {
         if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
         if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
@@ -1080,7 +1133,7 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
     WitnessDev wit;
     wit.n = n_assign;
     wit.z.alloc(n_assign * sizeof(Fr));
-    ZK_HIP(hipMemcpyAsync(wit.z.p, full_assignment, n_assign * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    upload_h2d(ctx, wit.z.p, full_assignment, n_assign * sizeof(Fr));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     const std::function<void()> upload = [&]() { r1cs_copy(ctx, *rc, rp, col, cf); };
     Partials p;

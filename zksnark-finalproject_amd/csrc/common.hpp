@@ -165,6 +165,8 @@ struct zkg16_ctx {
     hipStream_t wm_stream = nullptr;                  // witness map + h-side sort of a proof, concurrent with the z-side MSMs
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof
     void *extra_host = nullptr;                       // pinned staging for the r, s, -rs scalars
+    void *stage_host[2] = {nullptr, nullptr};         // pinned staging ring of upload_h2d (api.hip)
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
     float timings[16] = {0};
     bool kernel_timing = false;
