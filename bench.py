@@ -65,9 +65,9 @@ def parse():
     ap.add_argument("--h-ranks", type=int, default=0, help="N > 1, shard: ranks that run the witness map (0 = cost model; N = equal split)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="N = 1: after the timed region, also report throughput with this many proofs in flight (one ctx per host thread)")
-    ap.add_argument("--tables", default="auto", choices=["auto", "off"],
+    ap.add_argument("--tables", default="auto", choices=["auto", "on", "off"],
                     help="auto = window tables for the resident key (zkg16_pk_precompute; the plain key is timed first and reported "
-                         "beside it); off = plain key only")
+                         "beside it); on = the same without the plain-key proofs (profiling runs); off = plain key only")
     ap.add_argument("--seed", type=int, default=2026)
     return ap.parse_args()
 
@@ -236,7 +236,7 @@ def main():
         if args.tables == "off":
             return None
         plain_ms = None
-        if prove_once is not None:
+        if prove_once is not None and args.tables == "auto":
             prove_once()
             k = 3
             t_ = time.perf_counter()

@@ -223,6 +223,38 @@ def test_witness_map_vs_oracle(dev, oracle):
         dev.witness_free(wh)
 
 
+def test_witness_map_row_order_and_coefficient_dictionary(dev, oracle):
+    """The SpMV's two per-handle structures (csrc/poly.hip): rows ordered by length class (0 .. 254 non-zeros, and one class for
+    everything longer) and the 16-bit coefficient dictionary (here 37 distinct values, among them 1, -1 and 0; the random systems
+    of the other tests overflow it and exercise the fall-back).  Witness map == oracle, and == the plain kernel (option spmv_dict 2)."""
+    rng = random.Random(77)
+    nc, ni, nv = 9000, 3, 7000
+    pool = [1, P.R_MOD - 1, 0, 2, 3] + [P.rand_fr(rng) for _ in range(32)]
+    z = [1] + [P.rand_fr(rng) for _ in range(nv - 1)]
+    lens = [0, 1, 1, 1, 2, 5, 40, 300]
+    A, B, C = [], [], []
+    for i in range(nc):
+        rows = []
+        for _ in range(3):
+            k = lens[rng.randrange(len(lens))] if i % 11 else 1
+            cols = sorted(rng.sample(range(nv), k))
+            rows.append([(pool[rng.randrange(len(pool))], j) for j in cols])
+        A.append(rows[0]); B.append(rows[1]); C.append(rows[2])
+    r1cs = synth.r1cs_arrays(A, B, C, ni)
+    zm = fr_mont_vec(z)
+    rh, wh = dev.r1cs_load(r1cs, nv), dev.witness_load(zm)
+    want = oracle.witness_map(r1cs, zm)
+    assert np.array_equal(dev.witness_map(rh, wh, 1 << 14), want)
+    dev.set_option("spmv_dict", 2)
+    try:
+        assert np.array_equal(dev.witness_map(rh, wh, 1 << 14), want)
+    finally:
+        dev.set_option("spmv_dict", 0)
+    assert np.array_equal(dev.witness_map(rh, wh, 1 << 14), want)
+    dev.r1cs_free(rh)
+    dev.witness_free(wh)
+
+
 def test_prove_golden(dev):
     """Whole proofs against the golden Groth16 fixtures (expected A, B, C computed in the exponent by pyref)."""
     for case in load("groth16_kat.json"):

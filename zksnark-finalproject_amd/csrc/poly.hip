@@ -239,69 +239,104 @@ __global__ void __launch_bounds__(256) spmv_dict_kernel(SpmvDictArgs a) {
 // The reference's matrices mix rows of 1 non-zero (88 % of them) with rows of 4 .. 133 (the Poseidon rounds' linear layers), in
 // runs of every length: with a row per lane in natural order a wave runs as long as its longest row while most lanes idle —
 // the SpMV of the 128x128 circuit took 6.3 ms, 4 of them the multiplier at ~8 % lane utilisation.  The rows are therefore
-// ordered by length class (min(length, 255), longest first) once per handle: a counting sort with per-workgroup LDS histograms.
-// The order inside a class does not matter (every row is computed on its own), so it is left to the atomics.
-__global__ void __launch_bounds__(256) row_len_hist_kernel(const uint64_t *rp, size_t nc, uint32_t *hist) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < nc) {
-        const uint64_t len = rp[row + 1] - rp[row];
-        atomicAdd(&h[len > 255 ? 255u : (uint32_t)len], 1u);
-    }
-    __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
+// ordered once per handle by length class = bit length of the row's non-zero count (0, 1, 2-3, 4-7, ... : lanes of a wave
+// differ by less than 2x), longest class first, and in natural order inside a class: neighbouring rows read neighbouring
+// variables, and an order that shuffled them (exact-length classes filled through atomics) tripled the kernel's HBM reads.
+// Stable counting sort: per-workgroup class counts, a scan over the workgroups per class, ballot ranks inside the workgroup.
+static constexpr int ROW_CLASSES = 18;
+__device__ __forceinline__ uint32_t row_class(const uint64_t *rp, size_t row) {
+    const uint64_t len = rp[row + 1] - rp[row];
+    const uint32_t c = len ? 64u - (uint32_t)__builtin_clzll(len) : 0u;
+    return c < ROW_CLASSES ? c : ROW_CLASSES - 1;
 }
-// cursor[c] = first position of class c in the order (classes laid out longest first); advanced by each workgroup's share
-__global__ void __launch_bounds__(256) row_perm_kernel(const uint64_t *rp, size_t nc, uint32_t *cursor, uint32_t *perm) {
-    __shared__ uint32_t h[256], base[256];
-    h[threadIdx.x] = 0;
+__global__ void __launch_bounds__(256) row_class_count_kernel(const uint64_t *rp, size_t nc, uint32_t *counts /*[class][block]*/) {
+    __shared__ uint32_t h[ROW_CLASSES];
+    if (threadIdx.x < ROW_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cls = 0, mine = 0;
-    if (row < nc) {
-        const uint64_t len = rp[row + 1] - rp[row];
-        cls = len > 255 ? 255u : (uint32_t)len;
-        mine = atomicAdd(&h[cls], 1u);
+    if (row < nc) atomicAdd(&h[row_class(rp, row)], 1u);
+    __syncthreads();
+    if (threadIdx.x < ROW_CLASSES) counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+// one workgroup per class: counts[class][0 .. nblk) -> exclusive prefix; total -> tot[class]
+__global__ void __launch_bounds__(1024) row_class_scan_kernel(uint32_t *counts, uint32_t nblk, uint32_t *tot) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t *row = counts + (size_t)blockIdx.x * nblk;
+    const uint32_t per = ((nblk + nwv - 1) / nwv + 63u) & ~63u;
+    const uint32_t lo = wv * per, hi = lo + per < nblk ? lo + per : nblk;
+    uint32_t carry = 0;
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t v = i < hi ? row[i] : 0u;
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        carry += v;
     }
+    if (lane == 0) wave_tot[wv] = carry;
     __syncthreads();
-    base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(cursor + threadIdx.x, h[threadIdx.x]) : 0u;
+    uint32_t before = 0, total = 0;
+    for (uint32_t x = 0; x < nwv; x++) {
+        const uint32_t t = wave_tot[x];
+        if (x < wv) before += t;
+        total += t;
+    }
+    carry = before;
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < hi ? row[i] : 0u;
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += up;
+        }
+        if (i < hi) row[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) row_perm_kernel(const uint64_t *rp, size_t nc, const uint32_t *counts, const uint32_t *tot, uint32_t *perm) {
+    __shared__ uint32_t wcount[4][ROW_CLASSES], cbase[ROW_CLASSES];
+    const uint32_t wv = threadIdx.x >> 6;
+    if (threadIdx.x < ROW_CLASSES) {          // longest class first: everything of a larger class comes before this one
+        uint32_t b = 0;
+        for (int c = ROW_CLASSES - 1; c > (int)threadIdx.x; c--) b += tot[c];
+        cbase[threadIdx.x] = b + counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    }
+    for (uint32_t e = threadIdx.x; e < 4 * ROW_CLASSES; e += blockDim.x) (&wcount[0][0])[e] = 0;
     __syncthreads();
-    if (row < nc) {
-        const uint32_t pos = base[cls] + mine;
-        if (pos < nc) perm[pos] = (uint32_t)row;             // always true when the histogram was of these row pointers
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = row < nc;
+    const uint32_t cls = valid ? row_class(rp, row) : 0u;
+    uint64_t peers = __ballot(valid);          // the lanes of this wave with the same class
+    for (int b = 0; b < 5; b++) {
+        const bool bit = (cls >> b) & 1u;
+        const uint64_t mk = __ballot(valid && bit);
+        peers &= bit ? mk : ~mk;
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+    if (valid && below == 0) wcount[wv][cls] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+        uint32_t rank = below;
+        for (uint32_t x = 0; x < wv; x++) rank += wcount[x][cls];
+        const uint32_t pos = cbase[cls] + rank;
+        if (pos < nc) perm[pos] = (uint32_t)row;
     }
 }
 static void row_perm_build(zkg16_ctx *ctx, R1csDev &m) {
     const size_t nc = m.num_constraints;
     if (nc < 4096 || nc >= ((size_t)1 << 32)) return;
-    DevBuf hist(3 * 256 * sizeof(uint32_t));
-    ZK_HIP(hipMemsetAsync(hist.p, 0, 3 * 256 * sizeof(uint32_t), ctx->stream));
     const unsigned grid = (unsigned)((nc + 255) / 256);
-    for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL(row_len_hist_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, hist.as<uint32_t>() + 256 * i);
-    ZK_HIP(hipGetLastError());
-    uint32_t h[3 * 256];
-    ZK_HIP(hipMemcpyAsync(h, hist.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 3; i++) {
-        uint64_t run = 0;
-        for (int c = 255; c >= 0; c--) {                      // longest class first
-            const uint32_t cnt = h[256 * i + c];
-            h[256 * i + c] = (uint32_t)run;
-            run += cnt;
-        }
-        if (run != nc) return;                                // cannot happen; the natural order stays in use
-    }
-    ZK_HIP(hipMemcpyAsync(hist.p, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf counts(((size_t)ROW_CLASSES * grid + ROW_CLASSES) * sizeof(uint32_t));
+    uint32_t *cnt = counts.as<uint32_t>(), *tot = cnt + (size_t)ROW_CLASSES * grid;
     for (int i = 0; i < 3; i++) {
         m.perm[i].ensure(nc * sizeof(uint32_t));
-        hipLaunchKernelGGL(row_perm_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, hist.as<uint32_t>() + 256 * i,
-                           m.perm[i].as<uint32_t>());
+        hipLaunchKernelGGL(row_class_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, cnt);
+        hipLaunchKernelGGL(row_class_scan_kernel, dim3(ROW_CLASSES), dim3(1024), 0, ctx->stream, cnt, grid, tot);
+        hipLaunchKernelGGL(row_perm_kernel, dim3(grid), dim3(256), 0, ctx->stream, m.rp[i].as<uint64_t>(), nc, cnt, tot, m.perm[i].as<uint32_t>());
     }
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipStreamSynchronize(ctx->stream));               // `h` and `hist` go out of scope
+    ZK_HIP(hipStreamSynchronize(ctx->stream));               // `counts` goes out of scope
     m.perm_ok = true;
 }
 
