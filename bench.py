@@ -222,7 +222,8 @@ def main():
     setup_s = time.perf_counter() - t0
     plan, h_ranks = None, 1
     if sharded:
-        plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks, z_costs(circ.r1cs, circ.z, circ.num_instance))
+        plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks, z_costs(circ.r1cs, circ.z, circ.num_instance),
+                                   window_tables=args.tables != "off")
         z_lo, z_hi, h_lo, h_hi, blind = plan[rank]
         full = ph
         ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device; the whole key is dropped again

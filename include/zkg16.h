@@ -104,6 +104,9 @@ ZKG16_API int zkg16_pk_table_bits(zkg16_ctx *ctx, uint64_t pk_handle, int *windo
  * at infinity, the G2 one counted 2.8x); with it the z ranges are cut by cumulative cost instead of by index count. */
 ZKG16_API int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost,
                      uint64_t *ranges /* n_ranks x 4 */, uint8_t *blinding /* n_ranks */, int *h_ranks_out);
+/* The same plan with the cost factors of shards that carry window tables (window_tables != 0; zkg16_pk_precompute on every shard). */
+ZKG16_API int zkg16_shard_plan_tables(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost,
+                            int window_tables, uint64_t *ranges, uint8_t *blinding, int *h_ranks_out);
 ZKG16_API void zkg16_pk_free(zkg16_ctx *ctx, uint64_t pk_handle);
 
 /* ---- R1CS residency (ark_relations `ConstraintMatrices<Fr>` as CSR; matrices are per-circuit constants).

@@ -27,7 +27,7 @@ if 1 not in Gs:
     Gs = [1] + Gs
 for G in Gs:
     for force in ([0] if G == 1 else [0, G]):
-        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force, None if force else costs)
+        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force, None if force else costs, window_tables=tables)
         worst = 0.0
         per_rank = []
         seen = {}

@@ -34,6 +34,7 @@ SIGNATURES = {
     "zkg16_pk_precompute": (C.c_int, [ctxp, H, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "zkg16_pk_table_bits": (C.c_int, [ctxp, H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "zkg16_shard_plan": (C.c_int, [C.c_int, sz, sz, C.c_double, C.c_int, vp, u64p, u8p, C.POINTER(C.c_int)]),
+    "zkg16_shard_plan_tables": (C.c_int, [C.c_int, sz, sz, C.c_double, C.c_int, vp, C.c_int, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_pk_free": (None, [ctxp, H]),
     "zkg16_r1cs_load": (C.c_int, [ctxp] + [u64p, vp, vp] * 3 + [sz, sz, sz, C.POINTER(H)]),
     "zkg16_r1cs_free": (None, [ctxp, H]),

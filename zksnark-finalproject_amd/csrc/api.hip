@@ -858,12 +858,18 @@ static int default_window_bits(size_t n) {
 }
 int zkg16_shard_plan(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost, uint64_t *ranges,
                      uint8_t *blinding, int *h_ranks_out) {
+    return zkg16_shard_plan_tables(n_ranks, m_total, n_h, b_density, h_ranks, z_cost, 0, ranges, blinding, h_ranks_out);
+}
+int zkg16_shard_plan_tables(int n_ranks, size_t m_total, size_t n_h, double b_density, int h_ranks, const float *z_cost, int window_tables,
+                            uint64_t *ranges, uint8_t *blinding, int *h_ranks_out) {
     if (n_ranks < 1 || m_total == 0 || !ranges || !blinding || h_ranks < 0 || h_ranks > n_ranks) return ZKG16_ERR_BAD_ARG;
     if (!(b_density > 0.0) || b_density > 1.0) b_density = 0.8;
-    // calibrated on one MI355X playing every rank in turn (tools/shard_timing.py, profiles/shard_timing_r2.txt): the z side costs
-    // ~1.26x its additions (two digit / scatter passes, four bucket reductions), the h side ~1.1x, the witness map ~10.5 additions
-    // per domain element (27.6 ms at 2^24)
-    constexpr double KAPPA = 2.8, OMEGA = 10.5, Z_OVERHEAD = 1.26, H_OVERHEAD = 1.1;
+    // calibrated on one MI355X playing every rank in turn (tools/shard_calibrate.py, profiles/shard_calibration_r2.txt, 128x128):
+    // a z-only shard takes 3.6 ms + 108 ms x its fraction of the z cost (97 ms with window tables on the shard), an h-only shard
+    // 23.8 ms (the witness map) + 1.2 ms + 46.0 ms x its fraction of h_query (41.2 ms with tables).  In additions at 6.2 G/s:
+    // z side 1.33x (1.19x) its additions, h side 1.13x (1.015x), witness map 8.8 per domain element.
+    constexpr double KAPPA = 2.8, OMEGA = 8.8;
+    const double Z_OVERHEAD = window_tables ? 1.19 : 1.33, H_OVERHEAD = window_tables ? 1.015 : 1.13;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
     // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the

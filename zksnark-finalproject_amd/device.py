@@ -258,17 +258,18 @@ def z_costs(r1cs, z_mont, num_instance):
     return (entries * mult).astype(np.float32)
 
 
-def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0, z_cost=None):
-    """Rank roles of one proof over n_ranks GPUs (host-only zkg16_shard_plan) ->
+def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0, z_cost=None, window_tables=False):
+    """Rank roles of one proof over n_ranks GPUs (host-only zkg16_shard_plan / zkg16_shard_plan_tables) ->
     (list of (z_lo, z_hi, h_lo, h_hi, blinding) per rank, number of ranks that run the witness map).
-    z_cost: optional per-index costs (z_costs) so that the z ranges are cut by work, not by index count."""
+    z_cost: optional per-index costs (z_costs) so that the z ranges are cut by work, not by index count.
+    window_tables: the shards will carry window tables (pk_precompute): the cost factors measured for that case."""
     lib = _lib.load()
     ranges = np.zeros(4 * n_ranks, dtype=np.uint64)
     blind = np.zeros(n_ranks, dtype=np.uint8)
     k = C.c_int(0)
     zc = None if z_cost is None else np.ascontiguousarray(z_cost, dtype=np.float32)
     assert zc is None or zc.shape[0] == m_total
-    rc = lib.zkg16_shard_plan(n_ranks, m_total, n_h, float(b_density), h_ranks, _ptr(zc), ranges, blind, C.byref(k))
+    rc = lib.zkg16_shard_plan_tables(n_ranks, m_total, n_h, float(b_density), h_ranks, _ptr(zc), int(bool(window_tables)), ranges, blind, C.byref(k))
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
     r = ranges.reshape(n_ranks, 4)
