@@ -323,14 +323,18 @@ def main():
         if not args.no_e2e:
             try:
                 r, s = rs[-1]
-                t1 = time.perf_counter()
-                c2, syn2, _ = synthesize(args.workload, args.matrix_n)
-                t2 = time.perf_counter()
-                p2, i2 = dev.prove(ph, r, s, c2.r1cs, c2.z)
-                t3 = time.perf_counter()
+                first = None
+                for _ in range(2):          # a server's steady state: the second request (the first also allocates the pinned upload ring)
+                    t1 = time.perf_counter()
+                    c2, syn2, _ = synthesize(args.workload, args.matrix_n)
+                    t2 = time.perf_counter()
+                    p2, i2 = dev.prove(ph, r, s, c2.r1cs, c2.z)
+                    t3 = time.perf_counter()
+                    if first is None:
+                        first = t3 - t1
                 ok2 = verify(vk, c2.public_inputs, p2, i2)
                 e2e = {"seconds": t3 - t1, "proofs_per_sec": 1.0 / (t3 - t1), "constraints_per_sec": shp["nc"] / (t3 - t1),
-                       "host_synthesis_s": t2 - t1, "prove_host_pointers_s": t3 - t2, "proof_verified": bool(ok2),
+                       "host_synthesis_s": t2 - t1, "prove_host_pointers_s": t3 - t2, "first_request_s": first, "proof_verified": bool(ok2),
                        "note": "host synthesis (C++ mirror, full R1CS + assignment) + zkg16_prove with host pointers (matrices and "
                                "assignment uploaded over PCIe inside the call); the key stays resident, as the reference holds its pk"}
                 if args.workload == "matrix":

@@ -115,10 +115,11 @@ struct R1csDev {
     size_t nnz[3] = {0, 0, 0};
     // coefficient dictionary (poly.hip): R1CS coefficients are a few hundred distinct field elements (215 in the 128x128
     // MatrixCircuit's 86.6 M non-zeros), so the SpMV reads a 16-bit index per non-zero instead of 32 bytes.  Built on the
-    // device the first time the witness map runs on this handle; dict_state: 0 = not tried, 1 = in use, 2 = too many distinct values
+    // device the second time the witness map runs on this handle (a handle used once never pays for it); dict_state: 0 = not tried, 1 = in use, 2 = too many distinct values
     DevBuf ci[3], dict;
     uint32_t ndict = 0;
     int dict_state = 0;
+    int spmv_uses = 0;              // witness maps run on this handle so far (the structures are built on the second)
     // rows ordered by length, longest first (poly.hip): lane t of the SpMV takes row perm[t], so the 64 rows of a wave have about
     // the same number of non-zeros.  Built with the dictionary; null = natural order
     DevBuf perm[3];
