@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--h-ranks", type=int, default=0, help="N > 1, shard: ranks that run the witness map (0 = cost model; N = equal split)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="N = 1: after the timed region, also report throughput with this many proofs in flight (one ctx per host thread)")
+    ap.add_argument("--no-replicas-leg", action="store_true",
+                    help="N > 1, shard: skip the extra leg that times every rank proving its own proofs on the whole key (weak scaling)")
     ap.add_argument("--tables", default="auto", choices=["auto", "on", "off"],
                     help="auto = window tables for the resident key (zkg16_pk_precompute; the plain key is timed first and reported "
                          "beside it); on = the same without the plain-key proofs (profiling runs); off = plain key only")
@@ -220,14 +222,16 @@ def main():
     t0 = time.perf_counter()
     ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
     setup_s = time.perf_counter() - t0
-    plan, h_ranks = None, 1
+    plan, h_ranks, full = None, 1, None
     if sharded:
         plan, h_ranks = shard_plan(world, circ.num_vars, circ.domain - 1, 0.0, args.h_ranks, z_costs(circ.r1cs, circ.z, circ.num_instance),
                                    window_tables=args.tables != "off")
         z_lo, z_hi, h_lo, h_hi, blind = plan[rank]
         full = ph
-        ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device; the whole key is dropped again
-        dev.pk_free(full)
+        ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device
+        if args.no_replicas_leg:
+            dev.pk_free(full)                                       # the whole key is dropped again
+            full = None
     wh = dev.witness_load(circ.z)
     rng = np.random.default_rng(99)
     rs = [(fr_mont(int.from_bytes(rng.bytes(31), "little")), fr_mont(int.from_bytes(rng.bytes(31), "little"))) for _ in range(args.steps + args.warmup + 2)]
@@ -353,6 +357,35 @@ def main():
                 extra_out["end_to_end"] = e2e
             except Exception as e:      # noqa: BLE001
                 extra_out["end_to_end"] = {"error": repr(e)}
+
+    # ---- N > 1, shard: the same ranks as independent provers (every rank its own proofs on the whole key, no exchange) — the
+    # throughput a server farm would get from N GPUs, beside the one-proof latency the sharded path is about
+    replicas = None
+    if sharded and not args.no_replicas_leg and full is not None:
+        k_r = max(2, min(args.steps, 5))
+        dt_r, ok_r, err_r = float("inf"), False, None
+        barrier()
+        try:
+            if args.tables != "off" and args.dist_backend == "nccl":      # (rehearsals put several ranks on one GPU: no room for N tables)
+                dev.pk_precompute(full)
+            p_r = dev.prove_resident(full, rh, wh, *rs[0])
+            torch.cuda.synchronize()
+            t_r = time.perf_counter()
+            for j in range(k_r):
+                p_r = dev.prove_resident(full, rh, wh, *rs[j % len(rs)])
+            torch.cuda.synchronize()
+            dt_r = time.perf_counter() - t_r
+            ok_r = bool(verify(vk, circ.public_inputs, *p_r))
+        except Exception as e:      # noqa: BLE001 - every rank still reaches the reduction below
+            err_r = repr(e)
+        t_all = torch.tensor([dt_r if ok_r else 1e30], dtype=torch.float64, device=xdev)
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        worst = float(t_all.item())
+        replicas = ({"value": world * k_r / worst, "unit": "proofs/s", "proofs_per_rank": k_r, "ms_per_proof_per_rank": worst / k_r * 1e3,
+                     "scaling": "weak", "proofs_verified": True,
+                     "note": "every rank proves its own proofs on the whole key (window tables when each rank has its own GPU), no exchange; "
+                             "max over ranks; outside the contract's timed region"} if worst < 1e29 else {"error": err_r or "a rank failed"})
+        dev.pk_free(full)
 
     in_flight = None
     if world == 1 and args.in_flight > 1:
@@ -487,6 +520,8 @@ def main():
                                   "occupancy (tools/microbench.hip; profiles/bench_constants_r2.json names the log)"}
         out.update(extra_out)
         out["window_tables"] = tables_info
+        if replicas:
+            out["replicas_throughput"] = replicas
         if legs:
             out["legs"] = legs
         if in_flight:
