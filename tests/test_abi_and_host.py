@@ -138,8 +138,8 @@ def test_shard_plan_partitions_every_range(ranks, m, nh):
     """zkg16_shard_plan (host-only): the z ranges and the h ranges each partition their index space exactly, exactly one rank
     carries the blinding terms and that rank has z work, h ranges live on the first k ranks only, and forcing k is honoured."""
     from zksnark_finalproject_amd.device import shard_plan
-    for force in (0, 1, ranks):
-        plan, k = shard_plan(ranks, m, nh, 0.0, force)
+    for force, tables in ((0, False), (1, False), (ranks, False), (0, True), (ranks, True)):      # tables: zkg16_shard_plan_tables' factors
+        plan, k = shard_plan(ranks, m, nh, 0.0, force, None, tables)
         assert len(plan) == ranks and 1 <= k <= ranks and (force == 0 or k == force)
         pos = 0
         for z_lo, z_hi, _, _, _ in plan:
@@ -157,10 +157,11 @@ def test_shard_plan_partitions_every_range(ranks, m, nh):
         blind = [p for p in plan if p[4]]
         assert len(blind) == 1 and blind[0][1] > blind[0][0]
     if ranks == 8 and m > 1000000:          # the headline config: the model must not fall back to "every rank repeats the witness map"
-        plan, k = shard_plan(ranks, m, nh)
-        assert k < ranks
-        z_sizes = [p[1] - p[0] for p in plan]
-        assert max(z_sizes[k:]) > max(z_sizes[:k])      # witness-map ranks take less z work
+        for tables in (False, True):
+            plan, k = shard_plan(ranks, m, nh, window_tables=tables)
+            assert k < ranks
+            z_sizes = [p[1] - p[0] for p in plan]
+            assert max(z_sizes[k:]) > max(z_sizes[:k])      # witness-map ranks take less z work
 
 
 def test_combine_partials_with_rank_roles(oracle):
