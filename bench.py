@@ -303,6 +303,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item())
     stages = dev.last_timings()
+    term_counts = dev.last_term_counts()          # sorted term-list lengths of the last proof: exact mixed additions per MSM
     acc = dev.kernel_stats("msm_accumulate_g1")
     acc2 = dev.kernel_stats("msm_accumulate_g2")
 
@@ -511,13 +512,19 @@ def main():
                 return 254 // (17 if n >= (1 << 23) else 16 if n >= (1 << 20) else 15 if n >= (1 << 17) else 13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
             z_entries = (nz - n_one - n_zero) * nwin(nz, tables_info["window_bits_z"] if tables_info else 0) + n_one
             h_entries = nh * nwin(nh, tables_info["window_bits_h"] if tables_info else 0)
-            gadd = (3 * z_entries + h_entries) / 4.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            est = (3 * z_entries + h_entries) / 4.0
+            # exact: A and L walk the z list, B1 the B list (or the z list), H the h list — lengths read back from the device
+            zc, bc, hc = term_counts
+            exact = (2 * zc + (bc if bc else zc) + hc) / 4.0
+            gadd = exact / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
             out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": peak, "unit": "G mixed additions/s",
                           "frac": (gadd / peak) if peak else None,
-                          "note": "entries = one per window for every scalar other than 0 and 1 (B1's density filter not counted: slight "
-                                  "over-estimate); peak = the same XYZZ mixed addition in a bare register-resident loop at the kernel's "
-                                  "occupancy (tools/microbench.hip; profiles/bench_constants_r2.json names the log)"}
+                          "additions_per_launch": exact, "term_lists": {"z": zc, "b": bc, "h": hc}, "additions_per_launch_estimate": est,
+                          "note": "additions = lengths of the sorted term lists of the last proof, read back from the device "
+                                  "(zkg16_last_term_counts): A and L walk the z list, B1 the B list, H the h list; peak = the same XYZZ "
+                                  "mixed addition in a bare register-resident loop at the kernel's occupancy (tools/microbench.hip; "
+                                  "profiles/bench_constants_r2.json names the log)"}
         out.update(extra_out)
         out["window_tables"] = tables_info
         if replicas:

@@ -261,6 +261,9 @@ ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t 
  * [0] spmv, [1] ntt+pointwise, [2] msm digits+sort, [3] msm H, [4] msm L, [5] msm A, [6] msm B1, [7] msm B2,
  * [8] host tail, [9] total wall.  Returns the number of entries written. */
 ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
+/* Lengths of the sorted (scalar, window) term lists of the last proof on this ctx = mixed additions of each MSM that walks the list:
+ * [0] the z list (A and L), [1] the B list (B1 and B2; 0 = they used the z list), [2] the h list.  Synchronises the ctx. */
+ZKG16_API int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]);
 /* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0 off, 1 every kernel family, 2 only the
  * bucket-accumulation launches (five event pairs per proof instead of ~60).  stats are accumulated per kernel name since
  * the last reset. */

@@ -255,6 +255,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     out.h = out.l = out.a = out.b1 = G1XYZZ::inf();
     out.b2 = G2XYZZ::inf();
     ZK_HIP(hipEventRecord(ev[0], ctx->stream));
+    ctx->ws_z.last_tb = ctx->ws_zb.last_tb = ctx->ws_h.last_tb = 0;
     const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
     MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
     const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
@@ -686,7 +687,7 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "acc_debug")) {          // timing probes of the accumulation kernels; results are WRONG while set
-        if (value < 0 || value > 3) return ZKG16_ERR_BAD_ARG;
+        if (value < 0 || value > 15) return ZKG16_ERR_BAD_ARG;
         ctx->opt_acc_debug = (int)value;
         return ZKG16_OK;
     }
@@ -1367,6 +1368,22 @@ int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap) {
     const int n = cap < 10 ? cap : 10;
     for (int i = 0; i < n; i++) ms[i] = ctx->timings[i];
     return n;
+}
+
+// Lengths of the sorted (scalar, window) term lists of the last proof on this ctx = mixed additions per MSM that uses the list:
+// [0] the z list (A and L), [1] the B list (B1 and B2; 0 = they used the z list), [2] the h list.  Synchronises the ctx.
+int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]) {
+    if (!counts) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    ZK_HIP(hipDeviceSynchronize());
+    MsmWorkspace *w[3] = {&ctx->ws_z, &ctx->ws_zb, &ctx->ws_h};
+    for (int i = 0; i < 3; i++) {
+        uint32_t v = 0;
+        if (w[i]->last_tb && w[i]->offsets.p)
+            ZK_HIP(hipMemcpy(&v, w[i]->offsets.as<uint32_t>() + w[i]->last_tb, sizeof v, hipMemcpyDeviceToHost));
+        counts[i] = v;
+    }
+    ZK_API_END(ctx)
 }
 
 int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {

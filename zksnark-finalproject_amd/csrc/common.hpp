@@ -148,6 +148,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 
 struct MsmWorkspace {       // grown on demand, reused across proofs
     DevBuf keys, entries, offsets, seg_params, scalars, stage, sort_temp, codes;
+    size_t last_tb = 0;         // offsets[last_tb] = length of the term list built last (0: none) — zkg16_last_term_counts
 };
 
 }  // namespace zk

@@ -171,7 +171,7 @@ struct AccArgs {
     const uint32_t *total_ptr;  // number of sorted entries (= offsets[total_buckets]); read on the device, no host sync
     size_t total_buckets;
     const uint32_t *seg_len_ptr; // entries per lane, computed on the device from the exact entry count (msm_seg_params_kernel)
-    uint32_t debug;              // timing probes only (option "acc_debug"; results are WRONG): bit 0 = no bucket stores, bit 1 = always gather base 0
+    uint32_t debug;              // timing probes only (option "acc_debug"; results are WRONG): bit 0 = no bucket stores, bit 1 = always gather base 0, bit 2 = gathers from the first 64 K bases only
 };
 
 // G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
@@ -195,18 +195,48 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
     // first part is a device-function call, and a call drains all outstanding loads, so a gather issued earlier would be
     // waited for at once; the second part is one inlined product (~600 instructions, no call), long enough to cover it.
     if constexpr (PIPE) {
+        // G1: a finished bucket is not stored where it ends.  Its 14 stores would be in flight when the next field product is
+        // called, and a call waits for ALL outstanding memory operations — measured 4.5 % of the kernel.  The sum is parked in
+        // LDS (FLUSH_SLOTS lanes per iteration; further lanes of the same iteration store directly) and written out between
+        // the two parts of the addition, next to the gather, where the inlined product covers it.
+        constexpr bool DEFER = !FieldTraits<F>::g2;
+        constexpr int FLUSH_SLOTS = 16, WORDS = (int)(sizeof(XYZZ<F>) / 4);
+        __shared__ uint32_t flush_stage[DEFER ? FLUSH_SLOTS * WORDS : 1];
+        XYZZ<F> *pend_dst = nullptr;
+        uint32_t pend_slot = 0;
         uint2 en1 = start + 1 < end ? a.entries[start + 1] : en;
         Affine<F> bq = ldv(a.bases + (en.x >> 1));
         for (uint32_t p = start; p < end; p++) {
-            const uint32_t e = en.x, gb = en.y;
+            const uint32_t e = en.x, gb = (a.debug & 8u) ? cur : en.y;      // bit 3: never leave the first bucket (no flush code runs)
             if (gb != cur) {
                 // a bucket that began in an earlier segment is this segment's HEAD partial; one that continues into the
                 // next is its TAIL partial (a bucket doing both is recorded as head only); everything else is complete.
+                XYZZ<F> *dst = nullptr;
                 if (cur == g_first && head_open) {
                     head_b = (int32_t)cur;
-                    if (!(a.debug & 1u)) stv(a.seg_head + t, acc);
+                    dst = a.seg_head + t;
                 } else if (!acc.is_inf()) {
-                    if (!(a.debug & 1u)) stv(a.buckets + cur, acc);        // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+                    dst = a.buckets + cur;                                   // buckets[] is pre-zeroed = infinity (cur != g_after: it ended here)
+                }
+                if (a.debug & 1u) dst = nullptr;
+                if constexpr (DEFER) {
+                    const uint64_t want = __ballot(dst != nullptr);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (dst != nullptr && rank < (uint32_t)FLUSH_SLOTS) {
+#pragma unroll
+                        for (int k = 0; k < 14; k++) {
+                            flush_stage[(k) * FLUSH_SLOTS + rank] = acc.x.l[k];
+                            flush_stage[(14 + k) * FLUSH_SLOTS + rank] = acc.y.l[k];
+                            flush_stage[(28 + k) * FLUSH_SLOTS + rank] = acc.zz.l[k];
+                            flush_stage[(42 + k) * FLUSH_SLOTS + rank] = acc.zzz.l[k];
+                        }
+                        pend_dst = dst;
+                        pend_slot = rank;
+                    } else if (dst != nullptr) {
+                        stv(dst, acc);
+                    }
+                } else if (dst != nullptr) {
+                    stv(dst, acc);
                 }
                 acc = XYZZ<F>::inf();
                 cur = gb;
@@ -217,7 +247,21 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
             // result with the old value, and those wait for it at once.  The last iteration re-reads its own entry / base.
             en = en1;
             en1 = a.entries[p + 2 < end ? p + 2 : end - 1];
-            bq = ldv(a.bases + ((a.debug & 2u) ? 0u : (en.x >> 1)));
+            bq = ldv(a.bases + ((a.debug & 2u) ? 0u : (a.debug & 4u) ? ((en.x >> 1) & 0xffffu) : (en.x >> 1)));      // bit 2: gathers confined to 64 K bases (cache-resident)
+            if constexpr (DEFER) {
+                if (pend_dst != nullptr) {
+                    XYZZ<F> v;
+#pragma unroll
+                    for (int k = 0; k < 14; k++) {
+                        v.x.l[k] = flush_stage[(k) * FLUSH_SLOTS + pend_slot];
+                        v.y.l[k] = flush_stage[(14 + k) * FLUSH_SLOTS + pend_slot];
+                        v.zz.l[k] = flush_stage[(28 + k) * FLUSH_SLOTS + pend_slot];
+                        v.zzz.l[k] = flush_stage[(42 + k) * FLUSH_SLOTS + pend_slot];
+                    }
+                    stv(pend_dst, v);
+                    pend_dst = nullptr;
+                }
+            }
             asm volatile("" ::: "memory");            // the loads above stay above the inlined product
             xyzz_madd_finish(acc, tail, normal);
         }
@@ -627,8 +671,10 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
     plan.nwin = tabled ? 1 : plan.nwin_digits;
     plan.nb = (size_t)1 << (plan.c - 1);
     plan.total_entries = 0;
+    ws.last_tb = 0;
     if (n == 0) return;
     const size_t tb = plan.nb * plan.nwin;
+    ws.last_tb = tb;
     const size_t tot = n * (size_t)plan.nwin_digits;
     if (tot >= ((size_t)1 << 31)) throw HipError{hipErrorInvalidValue, "msm: more than 2^31 (scalar, window) terms", __FILE__, __LINE__};
     ws.entries.ensure(tot * sizeof(uint64_t));
@@ -666,7 +712,9 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
     // the exact entry count stays on the device (offsets[tb]); the accumulation grids are one resident round of waves and
     // the per-lane segment length is derived from the count on the device
     plan.total_entries = tot;
-    plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * (uint32_t)(ctx->opt_g1_waves > 0 ? ctx->opt_g1_waves : 2) * 64u;
+    // G1: two waves per SIMD, four from 2^25 terms on (124 registers: four fit; the extra waves hide what is left of the gather
+    // latency — 128x128: 163.0 -> 160.8 ms; no change at 32x32, where a lane would get ~25 terms)
+    plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * (uint32_t)(ctx->opt_g1_waves > 0 ? ctx->opt_g1_waves : tot >= ((size_t)1 << 25) ? 4 : 2) * 64u;
     plan.lanes_g2 = (uint32_t)ctx->num_cus * 4u * 1u * 64u;
     ws.seg_params.ensure(2 * sizeof(uint32_t));
     hipLaunchKernelGGL(msm_seg_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ws.offsets.as<uint32_t>() + tb, (uint32_t)tb, plan.lanes_g1,

@@ -78,6 +78,12 @@ class Device:
         self._check(self.lib.zkg16_pk_precompute(self.ctx, pk_h, int(window_bits_z), int(window_bits_h), C.byref(added)))
         return added.value
 
+    def last_term_counts(self):
+        """-> (z list, B list (0 = the z list was used), h list): mixed additions per MSM of the last proof (zkg16_last_term_counts)."""
+        out = (C.c_uint64 * 3)()
+        self._check(self.lib.zkg16_last_term_counts(self.ctx, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def pk_table_bits(self, pk_h):
         """-> (window bits of the z-side tables, of the h-side table); 0 = none (zkg16_pk_table_bits)."""
         bz, bh = C.c_int(0), C.c_int(0)
