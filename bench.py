@@ -396,6 +396,8 @@ def main():
             d2 = Device(dev_index)
             r2 = d2.r1cs_load(circ.r1cs, circ.num_vars)
             p2, _ = d2.setup_resident(r2, circ.num_instance, trap, g1, g2)
+            if args.tables != "off":
+                d2.pk_precompute(p2)
             extra.append((d2, p2, r2, d2.witness_load(circ.z)))
         lanes = [(dev, ph, rh, wh)] + extra
         per = max(args.steps, 4)
