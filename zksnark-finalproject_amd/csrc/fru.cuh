@@ -36,6 +36,11 @@ struct FrUP {
         constexpr uint32_t M[9] = {0x20000002u, 0x3fffffefu, 0x3f2dff7eu, 0x36900bfeu, 0x3b00aa76u, 0x380809a0u, 0x2a4199cdu, 0x34ca675eu, 0x00e7db4du};
         return M[i];
     }
+    // 4r with limbs 0..7 pre-borrowed: limb-wise "4r - b" never underflows for normalised b < 4r (butterflies with lazy sums)
+    ZK_HD static constexpr uint32_t m4(int i) {
+        constexpr uint32_t M[9] = {0x20000004u, 0x3fffffdfu, 0x3e5bfefeu, 0x2d2017feu, 0x360154eeu, 0x30101342u, 0x3483339cu, 0x2994cebdu, 0x01cfb69cu};
+        return M[i];
+    }
     ZK_HD static constexpr uint32_t c266(int i) {      // 2^266 mod r
         constexpr uint32_t M[9] = {0x1ffff72bu, 0x000046a7u, 0x1f5f3540u, 0x0ce3021cu, 0x118f3661u, 0x008176cbu, 0x054e487cu, 0x102e8190u, 0x001e092eu};
         return M[i];
@@ -65,7 +70,8 @@ ZK_HD void fru_normalise(FrU &a) {
     a.l[8] += c;
 }
 
-// a * b * 2^-261 mod r; limbs of a, b < 2^30 (need not be normalised), a * b < 70 r^2; result normalised, < 2r
+// a * b * 2^-261 mod r; limbs of a, b < 2^30 (need not be normalised; or a < 3 * 2^29 with b normalised), a * b < 70 r^2; result
+// normalised, < 2r
 ZK_HD FrU fru_mul(const FrU &a, const FrU &b) {
     constexpr int N = 9;
     uint32_t m[N];
@@ -110,6 +116,35 @@ ZK_HD FrU fru_sub_2r(const FrU &a, const FrU &b) {
     fru_normalise(r);
     return r;
 }
+// ---- the butterfly's own two operations (ntt.hip).  Values on the butterfly network are kept below 2r + e, e < 2^249:
+// a + b, minus 2r when the two TOP LIMBS already say the sum has reached 2r (no borrow chain, no second compare): one signed
+// carry pass does the addition, the subtraction and the normalisation.  With T = top limb of 2r: not subtracted -> the sum is
+// below (T + 3) 2^232 < 2r + 2^234; subtracted -> it was at least (T + 2) 2^232 > 2r, so the result is positive and below the
+// sum of the inputs' excesses + 2r — the excess e at most doubles per stage (2^234 -> 2^246 over the 12 stages of a pass) and
+// every pass ends in a product, which brings the value back below 2r.
+ZK_HD FrU fru_add_lazy(const FrU &a, const FrU &b) {
+    const uint32_t top = a.l[8] + b.l[8];
+    const bool sub = top > FrUP::two_r(8) + 1u;
+    FrU r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t v = (int32_t)(a.l[i] + b.l[i]) - (int32_t)(sub ? FrUP::two_r(i) : 0u) + c;
+        r.l[i] = (uint32_t)v & FrU::MASK;
+        c = v >> 29;                       // arithmetic shift: floor
+    }
+    r.l[8] = (uint32_t)((int32_t)top - (int32_t)(sub ? FrUP::two_r(8) : 0u) + c);
+    return r;
+}
+// a - b + 4r for normalised b < 4r, NOT normalised (limbs < 3 * 2^29): goes straight into fru_mul, whose columns hold
+// 9 x (3 * 2^29 x 2^29) + 9 x 2^58 < 2^63 with a normalised second operand
+ZK_HD FrU fru_sub_4r_raw(const FrU &a, const FrU &b) {
+    FrU r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (FrUP::m4(i) - b.l[i]);
+    return r;
+}
+
 // x >= c ? x - c : x   for normalised x, c = 2r (TWO = true) or r
 template <bool TWO>
 ZK_HD FrU fru_cond_sub(const FrU &x) {

@@ -238,12 +238,16 @@ __device__ __forceinline__ FrU tw_u(const uint32_t *s_tw, int tw_stride, int e, 
     }
     return lds_ld_u(s_tw, tw_stride, e);
 }
-// decimation-in-frequency butterfly on (x, y): x <- x + y (< 2r), y <- (x - y) * tw (< 2r); last stage: tw = 1
+// decimation-in-frequency butterfly on (x, y): x <- x + y (lazily reduced: < 2r + e, fru_add_lazy), y <- (x - y + 4r) * tw (< 2r);
+// last stage (tw = 1): y <- x - y + 4r as it is (< 6r + e, not normalised) — the store multiplies it by the pass's factor anyway.
+// (Until late in round 2: exact conditional subtraction of 2r after the sum and a normalised difference — 113 + 33 instructions
+// against 45 + 9; 2^24: 3.06 -> 2.94 ms per transform.  Keeping the 256 twiddles of the last nine stages of the 4096-point tiles in
+// the LDS left beside the tile instead of reading the global table: no change, 2.95 ms.)
 template <bool LAST>
 __device__ __forceinline__ void bfly_u(FrU &x, FrU &y, const FrU &tw) {
-    const FrU sum = fru_cond_sub<true>(fru_add(x, y));
-    const FrU dif = fru_sub_2r(x, y);
-    y = LAST ? fru_cond_sub<true>(dif) : fru_mul(dif, tw);
+    const FrU sum = fru_add_lazy(x, y);
+    const FrU dif = fru_sub_4r_raw(x, y);
+    y = LAST ? dif : fru_mul(dif, tw);
     x = sum;
 }
 
