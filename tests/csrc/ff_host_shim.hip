@@ -124,6 +124,18 @@ extern "C" void ht_fru_op(int op, const uint32_t *a, const uint32_t *b, uint32_t
             r = fru_mul(fru_sub_2r(xb, c), zc);
             break;
         }
+        case 8: {   // the butterflies' lazily reduced sum, twelve stages deep on the path that is never multiplied: x + 12 y
+            r = x;
+            for (int i = 0; i < 12; i++) r = fru_add_lazy(r, y);
+            break;
+        }
+        case 9: r = fru_mul(fru_sub_4r_raw(x, fru_add_lazy(fru_add_lazy(x, y), y)), y); break;      // (x - (x + 2y)) y: raw difference into the product
+        case 10: {  // last stage: the raw (un-normalised, < 6r) difference goes straight into the store's product
+            FrU s2 = x;
+            for (int i = 0; i < 11; i++) s2 = fru_add_lazy(s2, x);          // 12 x, as large as a lazily reduced value gets
+            st(o, fru_mul_to_sat(fru_sub_4r_raw(s2, y), fru_one_sat()));
+            return;
+        }
         default: r = x;
     }
     st(o, fru_mul_to_sat(r, fru_one_sat()));

@@ -221,7 +221,8 @@ def test_fru_ops_vs_python(shim):
     vals = [0, 1, 2, r - 1, r - 2, (1 << 254) % r, (1 << 255) % r] + [rng.randrange(r) for _ in range(60)]
     ops = ((0, lambda x, y: x + y), (1, lambda x, y: x - y), (2, lambda x, y: x * y), (3, lambda x, y: (x - y) * y),
            (4, lambda x, y: x * y), (5, lambda x, y: x * y), (6, lambda x, y: (x * y - y) * x * pow(32, -1, P.R_MOD)),
-           (7, lambda x, y: x * pow(32, -1, P.R_MOD)))
+           (7, lambda x, y: x * pow(32, -1, P.R_MOD)),
+           (8, lambda x, y: x + 12 * y), (9, lambda x, y: -2 * y * y), (10, lambda x, y: 12 * x - y))       # lazy butterfly sums / raw differences
     for a in vals[:9]:
         for b in vals[:9]:
             for op, f in ops:
