@@ -430,6 +430,11 @@ def test_window_tables_same_proof(dev, oracle, cz, ch):
     assert added == want                          # 0 for the default widths: both queries are far below 2^17 terms
     tabled = dev.prove_resident(ph, rh, wh, r, s)
     assert np.array_equal(tabled[0], plain[0]) and np.array_equal(tabled[1], plain[1])
+    # zkg16_last_term_counts: the sorted term lists of that proof = mixed additions per MSM (what bench.py's `alu` figure divides by)
+    zc, bc, hc = dev.last_term_counts()
+    digits = lambda c, n: 254 // c + 1 if c > 0 else 254 // (13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
+    assert 0 < zc <= (nv + 3) * digits(cz, nv + 3) and 0 < hc <= n_h * digits(ch, n_h) and bc <= zc
+    assert hc > n_h * (digits(ch, n_h) - 2)                  # h is dense: nearly every digit of every scalar is a term
     if cz > 0 or ch > 0:
         with pytest.raises(Zkg16Error) as e:
             dev.pk_precompute(ph, cz, ch)
