@@ -292,10 +292,11 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
     };
     // the z-side accumulations either start at once (their kernels and the witness map's then share the device) or wait for the
-    // witness map, which then has the device to itself and lets the h-side sort run underneath the accumulations.  Measured with
-    // window tables: 32x32 12.09 vs 12.41 ms, 46x46 19.9 vs 20.7, 128x128 171.85 vs 170.24 — so only from 2^23 on by default.
-    // (not when the matrices are still being uploaded on the witness map's stream: the accumulations are what hides that)
-    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : (rc.log_n >= 23 && !before_witness_map) ? 1 : 0;
+    // witness map, which then has the device to itself and lets the h-side sort run underneath the accumulations.  Measured: with
+    // window tables 128x128 154.5 vs 153.65 ms (32x32 11.7 vs 12.2, 46x46 19.7 vs 20.3), with a plain key 128x128 168.6 vs 171.2 —
+    // so by default only from 2^23 on and only for keys with tables; never when the matrices are still being uploaded on the
+    // witness map's stream (the accumulations are what hides that).
+    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : (rc.log_n >= 23 && pk.tab_c_h != 0 && !before_witness_map) ? 1 : 0;
     if (!wm_first) enqueue_z_accs();
 
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
@@ -696,16 +697,18 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_sort_mode = (int)value;
         return ZKG16_OK;
     }
-    if (!strcmp(name, "acc_pipeline")) {       // bit 0: G1, bit 1: G2 (default 3); 4 = both off (0 restores the default)
+    if (!strcmp(name, "acc_pipeline")) {       // bit 0: G1, bit 1: G2 software-pipelined gather; 0 (default) and 4: neither.  With four G1
+        // waves per SIMD and window tables the plain form (gather right before its addition) measured 153.6 against 157.4 ms per
+        // 128x128 proof, and the same at every other size and with plain keys (profiles/ab_options_r2_final.txt)
         if (value < 0 || value > 4) return ZKG16_ERR_BAD_ARG;
-        ctx->opt_acc_pipeline = value == 0 ? 3 : (value == 4 ? 0 : (int)value);
+        ctx->opt_acc_pipeline = value == 4 ? 0 : (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "fuse_pointwise")) {     // 1 (default): (ab - c)/Z on the load of the seventh transform; 0: own pass
         ctx->opt_fuse_pointwise = value ? 1 : 0;
         return ZKG16_OK;
     }
-    if (!strcmp(name, "wm_first")) {           // -1 (default): 1 from 2^23 on; 0: z-side accumulations start at once; 1: after the witness map; 2: after the h-side sort too
+    if (!strcmp(name, "wm_first")) {           // -1 (default): 1 from 2^23 on for keys with window tables; 0: z-side accumulations start at once; 1: after the witness map; 2: after the h-side sort too
         if (value < -1 || value > 2) return ZKG16_ERR_BAD_ARG;
         ctx->opt_wm_first = (int)value;
         return ZKG16_OK;

@@ -190,7 +190,7 @@ struct zkg16_ctx {
     int opt_ntt_xcd = 1;                              // NTT tiles in XCD-aware order (ntt.hip: xcd_tile)
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
-    int opt_acc_pipeline = 3;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product
+    int opt_acc_pipeline = 0;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product (default: neither)
     int opt_fuse_pointwise = 1;                       // (ab - c)/Z on the load of the seventh transform (0: its own pass)
     int num_cus = 256;
     bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
