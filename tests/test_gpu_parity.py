@@ -303,7 +303,7 @@ def test_prove_random_vs_oracle_and_exponent(dev, oracle):
     # every scheduling / tuning option leaves the proof bit-identical (the measured alternatives)
     for opt, vals in (("reduce_mode", (1, 2, 4, 0)), ("fixup_aux", (1, 0)), ("g1_waves", (1, 3, 4, 0)), ("window_bits_h", (9, 0)),
                       ("window_bits", (2, 3, 7, 11, 17, 0)), ("reduce_chunk", (4, 16, 0)), ("wm_concurrent", (0, -1)), ("fuse_pointwise", (0, 1)),
-                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0))):
+                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0)), ("b_filter", (1, 2, 0))):
         for v in vals:
             dev.set_option(opt, v)
             p3, i3 = dev.prove_resident(ph, rh, wh, fr_mont(r), fr_mont(s))
@@ -483,6 +483,10 @@ def test_window_tables_reference_circuits(dev, oracle, kind):
     tabled = dev.prove_resident(ph, rh, wh, r, s)
     assert np.array_equal(tabled[0], plain[0]) and np.array_equal(tabled[1], plain[1])
     assert verify(vk, c.public_inputs, *tabled)
+    for v in (2, 1, 0):         # the B-side term list by a second sort / filtered out of the full list (the default with tables)
+        dev.set_option("b_filter", v)
+        again = dev.prove_resident(ph, rh, wh, r, s)
+        assert np.array_equal(again[0], plain[0]) and np.array_equal(again[1], plain[1]), v
     for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
         f(hnd)
 

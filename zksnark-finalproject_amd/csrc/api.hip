@@ -271,8 +271,14 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         const int tz = pk.tab_c_z;
         msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z, tz, tz != 0);
         if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
-            zsrc.mask = pk.b_mask.as<uint8_t>();
-            msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb, tz, tz != 0);
+            // (measured: 128x128 with window tables 154.5 -> 153.65 ms, 32x32 11.97 -> 11.68; with a plain key 168.55 -> 169.2, so only with tables
+            // unless option b_filter = 1 asks for it)
+            if ((ctx->opt_b_filter == 1 || (ctx->opt_b_filter == 0 && tz != 0)) && ctx->opt_sort_mode == 0) {
+                msm_plan_filter(ctx, ctx->ws_z, plan_z, pk.b_mask.as<uint8_t>(), ctx->ws_zb, plan_zb);
+            } else {
+                zsrc.mask = pk.b_mask.as<uint8_t>();
+                msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb, tz, tz != 0);
+            }
         }
     }
     ZK_HIP(hipEventRecord(ev[1], ctx->stream));
@@ -716,6 +722,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "spmv_dict")) {          // 0 / 1 (default): 16-bit coefficient dictionary in the SpMV; 2: 32-byte coefficients
         if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
         ctx->opt_spmv_dict = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "b_filter")) {           // B-side term list = the sorted full list minus the masked terms: 0 (default) with window tables, 1 always; 2: second sort
+        if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_b_filter = (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "reduce_chunk")) {

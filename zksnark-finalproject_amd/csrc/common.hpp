@@ -179,6 +179,7 @@ struct zkg16_ctx {
     int opt_min_seg = 0;                              // shortest per-lane run of sorted entries in an accumulation (0 = default)
     int opt_ntt_mode = 1;                             // 1: unsaturated (29-bit limb) butterflies, 0: saturated
     int opt_reduce_mode = 3;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level, 2 = 1 except the proof's last MSM, 3 (default) = 2 from 16-bit windows on
+    int opt_b_filter = 0;                             // B-side term list filtered out of the full one: 0 = with window tables (default), 1 = always, 2 = never (second sort)
     int opt_spmv_dict = 0;                            // 0/1: coefficient dictionary in the SpMV (default); 2: plain kernel
     int opt_wm_first = -1;                            // see zkg16_set_option "wm_first"
     int opt_g1_waves = 0;                             // G1 accumulation waves per SIMD in the one resident round (0 = 2)
@@ -244,6 +245,8 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
 // window tables of a resident key: bases[n] -> new buffer [254 / c + 1][n], level w = 2^(c w) * base (msm.hip)
 DevBuf msm_tables_build_g1(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c);
 DevBuf msm_tables_build_g2(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c);
+// the term list of `plan_src` without the terms whose scalar index i has mask[i] != 0 (stable compaction; msm.hip)
+void msm_plan_filter(zkg16_ctx *ctx, const MsmWorkspace &ws_src, const MsmPlan &plan_src, const uint8_t *mask, MsmWorkspace &ws_dst, MsmPlan &plan_dst);
 void msm_sort_keys(zkg16_ctx *ctx, MsmWorkspace &ws, size_t count, unsigned key_bits);   // sort.hip (rocPRIM radix sort; option sort_mode 1)
 // bucket_sort.hip: hand-written wave-ballot counting scatter (default); returns the per-window entry counts (device)
 const uint32_t *msm_bucket_sort(zkg16_ctx *ctx, MsmWorkspace &ws, const uint32_t *codes, size_t n, int nwin, int c, uint2 *entries);

@@ -722,6 +722,135 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
     ZK_HIP(hipGetLastError());
 }
 
+// ---- the B-side term list as a FILTER of the full one.  B1 and B2 skip the terms whose base is the point at infinity in both B
+// queries (mask[i] != 0).  Sorting the scalars a second time with those zeroed costs a whole digit + scatter run (3.5 ms at
+// 128x128); the sorted full list minus the masked terms is the same list (the scatter is stable, and the masked terms are
+// simply absent), so it is produced by one stable compaction: per-workgroup counts of kept terms, a scan, ballot ranks.
+static constexpr int FILTER_CHUNK = 2048;        // terms per workgroup (256 threads x 8)
+__device__ __forceinline__ bool filter_keep(uint2 e, uint32_t n, double inv_n, const uint8_t *mask) {
+    const uint32_t idx = e.x >> 1;                               // window * n + i with window tables, i without
+    uint32_t q = (uint32_t)((double)idx * inv_n);
+    uint32_t i = idx - q * n;
+    if ((int32_t)i < 0) i += n; else if (i >= n) i -= n;         // the estimate of q is off by at most one
+    return mask[i] == 0;
+}
+__global__ void __launch_bounds__(256) filter_count_kernel(const uint2 *in, const uint32_t *total_ptr, uint32_t n, double inv_n, const uint8_t *mask,
+                                                           uint32_t *block_counts) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t total = *total_ptr;
+    const size_t base = (size_t)blockIdx.x * FILTER_CHUNK;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < FILTER_CHUNK / 256; r++) {
+        const size_t k = base + (size_t)r * 256 + threadIdx.x;
+        if (k < total && filter_keep(in[k], n, inv_n, mask)) mine++;
+    }
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// one workgroup: exclusive scan of the per-workgroup counts (in place); counts[nblk] = total kept
+__global__ void __launch_bounds__(1024) filter_scan_kernel(uint32_t *counts, uint32_t nblk) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t per = ((nblk + 15u) / 16u + 63u) & ~63u;
+    const uint32_t lo = wv * per, hi = lo + per < nblk ? lo + per : nblk;
+    uint32_t carry = 0;
+    for (uint32_t b = lo; b < hi; b += 64) {
+        const uint32_t i = b + lane;
+        uint32_t v = i < hi ? counts[i] : 0u;
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        carry += v;
+    }
+    if (lane == 0) wave_tot[wv] = carry;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t x = 0; x < 16; x++) {
+        const uint32_t t = wave_tot[x];
+        if (x < wv) before += t;
+        total += t;
+    }
+    carry = before;
+    for (uint32_t b = lo; b < hi; b += 64) {
+        const uint32_t i = b + lane;
+        const uint32_t v = i < hi ? counts[i] : 0u;
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += up;
+        }
+        if (i < hi) counts[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[nblk] = total;
+}
+__global__ void __launch_bounds__(256) filter_write_kernel(const uint2 *in, const uint32_t *total_ptr, uint32_t n, double inv_n, const uint8_t *mask,
+                                                           const uint32_t *block_base, uint2 *out) {
+    __shared__ uint32_t wcount[FILTER_CHUNK / 256][4];
+    const uint32_t total = *total_ptr;
+    const size_t base = (size_t)blockIdx.x * FILTER_CHUNK;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint2 e[FILTER_CHUNK / 256];
+    uint32_t below[FILTER_CHUNK / 256], keepmask = 0;
+#pragma unroll
+    for (int r = 0; r < FILTER_CHUNK / 256; r++) {
+        const size_t k = base + (size_t)r * 256 + threadIdx.x;
+        e[r] = make_uint2(0, 0);
+        bool keep = false;
+        if (k < total) {
+            e[r] = in[k];
+            keep = filter_keep(e[r], n, inv_n, mask);
+        }
+        const uint64_t peers = __ballot(keep);
+        below[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        if (lane == 0) wcount[r][wv] = (uint32_t)__popcll(peers);
+        if (keep) keepmask |= 1u << r;
+    }
+    __syncthreads();
+    uint32_t pos = block_base[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < FILTER_CHUNK / 256; r++) {       // element order = (round, wave, lane): the order of the input
+        uint32_t before = 0, round_total = 0;
+        for (uint32_t x = 0; x < 4; x++) {
+            if (x < wv) before += wcount[r][x];
+            round_total += wcount[r][x];
+        }
+        if (keepmask & (1u << r)) out[pos + before + below[r]] = e[r];
+        pos += round_total;
+    }
+}
+// plan_dst / ws_dst: the list of plan_src / ws_src without the terms whose scalar index is masked; same buckets, same widths
+void msm_plan_filter(zkg16_ctx *ctx, const MsmWorkspace &ws_src, const MsmPlan &plan_src, const uint8_t *mask, MsmWorkspace &ws_dst, MsmPlan &plan_dst) {
+    plan_dst = plan_src;
+    ws_dst.last_tb = 0;
+    if (plan_src.n == 0) return;
+    const size_t tb = plan_src.nb * plan_src.nwin, tot = plan_src.total_entries;
+    ws_dst.last_tb = tb;
+    ws_dst.entries.ensure(tot * sizeof(uint64_t));
+    ws_dst.offsets.ensure((tb + 1) * sizeof(uint32_t));
+    ws_dst.seg_params.ensure(2 * sizeof(uint32_t));
+    const uint32_t nblk = (uint32_t)((tot + FILTER_CHUNK - 1) / FILTER_CHUNK);
+    ws_dst.sort_temp.ensure(((size_t)nblk + 1) * sizeof(uint32_t));
+    uint32_t *counts = ws_dst.sort_temp.as<uint32_t>();
+    const uint32_t *total_src = ws_src.offsets.as<uint32_t>() + tb;
+    const uint32_t n = (uint32_t)plan_src.n;
+    const double inv_n = 1.0 / (double)n;
+    {
+        ScopedKernelTimer kt(ctx, "msm_plan_filter", (double)tot, ctx->stream);
+        hipLaunchKernelGGL(filter_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, ws_src.entries.as<uint2>(), total_src, n, inv_n, mask, counts);
+        hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, nblk);
+        hipLaunchKernelGGL(filter_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, ws_src.entries.as<uint2>(), total_src, n, inv_n, mask, counts,
+                           ws_dst.entries.as<uint2>());
+        hipLaunchKernelGGL(msm_offsets_kernel, dim3((unsigned)((tb + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ws_dst.entries.as<uint2>(), tot,
+                           counts + nblk, 1, ws_dst.offsets.as<uint32_t>(), tb);
+    }
+    hipLaunchKernelGGL(msm_seg_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ws_dst.offsets.as<uint32_t>() + tb, (uint32_t)tb, plan_dst.lanes_g1,
+                       plan_dst.lanes_g2, (uint32_t)(ctx->opt_min_seg > 0 ? ctx->opt_min_seg : 0), ws_dst.seg_params.as<uint32_t>());
+    ZK_HIP(hipGetLastError());
+}
+
 // An MSM runs in two halves on two HIP streams so that the latency-bound bucket reduction of one MSM overlaps the
 // throughput-bound bucket accumulation of the next:
 //   main stream: clear buckets -> accumulate -> fix-ups                      -> event acc_done
