@@ -341,7 +341,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     if (trace) fprintf(stderr, "host: z-side msms queued at %.3f ms\n", now_ms() - t0);
 
     // ---- H last: it is the only MSM that waits for the witness map; then collect — each MSM's host Horner overlaps the
-    // device work still queued behind it
+    // device work still queued behind it.  (With the witness map first H could go second — its list sorted underneath the G2
+    // accumulation — and L, with a quarter of H's buckets and nothing to do on the host afterwards, last: measured 154.7 against
+    // 153.65 ms, the shorter tail does not pay for the earlier scatter.)
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[4], 0));
     ctx->slots[1].last_of_proof = true;
     if (nh) msm_g1_enqueue(ctx, ctx->ws_h, plan_h, pk.h.as<G1AffineU>(), ctx->slots[1]);
