@@ -121,6 +121,8 @@ ZKG16_API void zkg16_r1cs_free(zkg16_ctx *ctx, uint64_t r1cs_handle);
 /* ---- full assignment z = instance || witness (Montgomery), n_assign x 4 limbs, uploaded once per proof. */
 ZKG16_API int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n_assign, uint64_t *witness_handle);
 ZKG16_API void zkg16_witness_free(zkg16_ctx *ctx, uint64_t witness_handle);
+/* the assignment behind a handle, copied back (n_assign must match the handle's length) */
+ZKG16_API int zkg16_witness_read(zkg16_ctx *ctx, uint64_t witness_handle, uint64_t *full_assignment_out, size_t n_assign);
 
 /* ---- the hot path.  r, s: Montgomery Fr (drawn by the caller exactly as ark-groth16 does: r then s).
  * proof_out = A (12) | B (24) | C (12) affine Montgomery limbs; inf_out[3] = infinity flags of A, B, C. */
@@ -225,6 +227,19 @@ ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, s
 ZKG16_API int zkg16_circuit_is_satisfied(const zkg16_circuit *c);
 ZKG16_API int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3],
                          uint64_t *full_assignment /* (num_instance + num_witness) x 4 */);
+/* ---- the MatrixCircuit's assignment built ON THE DEVICE (scope row f-4 "on GPU"; csrc/witness.hip).  The reference re-synthesises
+ * the circuit inside its timed `Groth16::prove` (matrix_proof.rs:138-145, constraints.rs:78-128): per request only the
+ * assignment changes, 75 % of which are the S-box products of 3 ceil(n^2/2) Poseidon permutations (hashing_utils.rs:737-802).
+ * The host runs the three native sponges (sequential by construction: hasher.rs:17-27) and keeps the state in front of every
+ * permutation; kernels write z in place — a, b as Fr, the n^3 products, 265 values per permutation — into a buffer
+ * zkg16_prove_resident reads.  *witness_handle: as from zkg16_witness_load of zkg16_circuit_matrix_witness's output (same bytes).
+ * public_inputs (nullable): hash_a | hash_b | hash_c, Montgomery.  timings_ms (nullable, 3 floats): host sponges, device
+ * (upload + kernels), whole call. */
+ZKG16_API int zkg16_witness_matrix(zkg16_ctx *ctx, size_t n, const uint64_t *a, const uint64_t *b, uint64_t *witness_handle,
+                         uint64_t public_inputs[12], float *timings_ms);
+/* Its host-only half (no ctx, no GPU): states (nullable) = 3 hashes x ceil(n^2/2) permutations x 3 Fr, the sponge state in
+ * front of each permutation (after its two elements were absorbed); hashes = hash_a | hash_b | hash_c. */
+ZKG16_API int zkg16_matrix_sponge_states(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *states, uint64_t hashes[12]);
 /* native Poseidon sponge hash of n Fr elements (Montgomery) — the public inputs hash_a/b/c of the matrix handler */
 ZKG16_API int zkg16_poseidon_hash(const uint64_t *elems, size_t n, uint64_t out[4]);
 

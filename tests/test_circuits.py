@@ -179,3 +179,31 @@ def test_assignment_only_build_equals_full_synthesis(n):
     assert np.array_equal(matrix_witness(a, b, c.num_vars), c.z)
     with pytest.raises(Zkg16Error):
         matrix_witness(a, b, c.num_vars + 1)
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8])
+def test_matrix_sponge_states_host_half_of_the_device_witness(n):
+    """zkg16_matrix_sponge_states (csrc/witness.hip, 64-bit-limb chains with lazily reduced linear layers) against the
+    pure-Python sponge: every recorded entering state, the three hashes, and c = a b with entries that overflow 64 bits."""
+    from zksnark_finalproject_amd.circuits import matrix_sponge_states, matrix_witness
+    from zksnark_finalproject_amd.workloads import matmul_shape
+    rng = np.random.default_rng(100 + n)
+    a = rng.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2) + np.uint64(1)       # full 64-bit entries
+    b = rng.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2)
+    states, hashes = matrix_sponge_states(a, b)
+    ai, bi = [[int(x) for x in row] for row in a], [[int(x) for x in row] for row in b]
+    ci = [[sum(ai[i][k] * bi[k][j] for k in range(n)) % R for j in range(n)] for i in range(n)]
+    flat = lambda m: [x for row in m for x in row]
+    for h, elems in enumerate((flat(ai), flat(bi), flat(ci))):
+        st, want = [0, 0, 0], []
+        for p in range((n * n + 1) // 2):
+            for pos, e in enumerate(elems[2 * p:2 * p + 2]):
+                st[1 + pos] = (st[1 + pos] + e) % R
+            want.append(list(st))
+            st = py_permute(st)
+        got = [fr_from_mont_vec(states[h, p]) for p in range(len(want))]
+        assert got == want, h
+        assert P.fr_from_mont(unlimbs(hashes[h])) == st[1]
+    # and the same hashes as the host-side assignment builder puts into z[1..3]
+    z = matrix_witness(a, b, matmul_shape(n)["num_witness"] + 4)
+    assert np.array_equal(z[1:4], hashes)

@@ -740,3 +740,90 @@ def test_prove_prime_like_bits_workload(dev, oracle):
     dev.pk_free(ph)
     eproof, einf = oracle.prove(pk, r, s, r1cs, zm)
     assert np.array_equal(proof, eproof) and np.array_equal(inf, einf)
+
+
+# ---------------------------------------------------------------------------------------------- device witness generation
+@pytest.mark.parametrize("n", [2, 5, 33, 46, 128])
+def test_witness_matrix_on_device_equals_host_builder(dev, n):
+    """zkg16_witness_matrix (scope row f-4 "on GPU"): the MatrixCircuit assignment written by the device kernels from the host
+    sponges' entering states == the host builder's (zkg16_circuit_matrix_witness, itself checked against the gadget-level
+    synthesis and a Python sponge in tests/test_circuits.py) byte for byte; random full-range u64 inputs (products up to 2^128,
+    sums above it), odd n (a last sponge block with one element) and the headline size."""
+    from zksnark_finalproject_amd.circuits import matrix_witness
+    from zksnark_finalproject_amd.workloads import matmul_shape
+    rng = np.random.default_rng(1000 + n)
+    a = rng.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, n), dtype=np.uint64)
+    b = rng.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, n), dtype=np.uint64)
+    nv = matmul_shape(n)["num_witness"] + 4
+    want = matrix_witness(a, b, nv)
+    wh, pub, ms = dev.witness_matrix(a, b)
+    got = dev.witness_read(wh, nv)
+    dev.witness_free(wh)
+    assert np.array_equal(pub, want[1:4])
+    if not np.array_equal(got, want):
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        raise AssertionError("device assignment differs from the host builder's at %d of %d variables, first %s" % (len(bad), nv, bad[:8]))
+    # all-ones inputs, the reference bench's workload (bench/matrix.py:11)
+    ones = np.ones((n, n), dtype=np.uint64)
+    wh, pub, _ = dev.witness_matrix(ones, ones)
+    assert np.array_equal(dev.witness_read(wh, nv), matrix_witness(ones, ones, nv))
+    dev.witness_free(wh)
+
+
+@pytest.mark.parametrize("n", [8, 32])
+def test_proof_from_device_witness_equals_proof_from_host_witness(dev, oracle, n):
+    """The whole request through the device-built assignment: same key, r, s -> the same proof bytes as with the host-built
+    assignment, which equal the oracle's."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    rng_np = np.random.default_rng(5 + n)
+    a = rng_np.integers(0, 1 << 40, size=(n, n), dtype=np.uint64)
+    b = rng_np.integers(0, 1 << 40, size=(n, n), dtype=np.uint64)
+    circ = matrix_circuit(a, b)
+    rng = random.Random(11 * n)
+    pk, _ = synth.make_pk(oracle, circ.r1cs, circ.num_witness, rng, point_gen=dev.fixed_base)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    ph = dev.pk_load(pk, circ.num_instance)
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    w_host = dev.witness_load(circ.z)
+    w_dev, pub, _ = dev.witness_matrix(a, b)
+    assert np.array_equal(pub, circ.public_inputs)
+    p_host = dev.prove_resident(ph, rh, w_host, r, s)
+    p_dev = dev.prove_resident(ph, rh, w_dev, r, s)
+    assert np.array_equal(p_host[0], p_dev[0]) and np.array_equal(p_host[1], p_dev[1])
+    eproof, einf = oracle.prove(pk, r, s, circ.r1cs, circ.z)
+    assert np.array_equal(p_dev[0], eproof) and np.array_equal(p_dev[1], einf)
+    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, w_host), (dev.witness_free, w_dev)):
+        f(h)
+
+
+def test_full_size_request_verifies_with_tables(dev):
+    """The headline MODE at the headline SIZE: 128x128, resident key -> plain proof -> window tables
+    (c = 20 / 22, three-pass scatter, B-list filter, four G1 waves per SIMD, witness map first) -> tabled proof == the plain
+    proof bit for bit -> pairing verification; the assignment comes from the device generator."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    from zksnark_finalproject_amd.device import verify
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    from zksnark_finalproject_amd.device import scalar_mul
+    n = 128
+    ones = np.ones((n, n), dtype=np.uint64)
+    circ = matrix_circuit(ones, ones)
+    rng = random.Random(128)
+    trap = np.stack([fr_mont(P.rand_fr(rng)) for _ in range(5)])
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    g1, g2 = scalar_mul("g1", g1_generator(), k)[0], scalar_mul("g2", g2_generator(), k)[0]
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
+    wh, pub, _ = dev.witness_matrix(ones, ones)
+    assert np.array_equal(pub, circ.public_inputs)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    plain = dev.prove_resident(ph, rh, wh, r, s)
+    dev.pk_precompute(ph)
+    assert dev.pk_table_bits(ph) == (20, 22)
+    tabled = dev.prove_resident(ph, rh, wh, r, s)
+    assert np.array_equal(plain[0], tabled[0]) and np.array_equal(plain[1], tabled[1])
+    assert verify(vk, circ.public_inputs, *tabled) is True
+    bad = circ.public_inputs.copy()
+    bad[2] = bad[0]
+    assert verify(vk, bad, *tabled) is False
+    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(h)

@@ -41,6 +41,7 @@ SIGNATURES = {
     "zkg16_r1cs_free": (None, [ctxp, H]),
     "zkg16_witness_load": (C.c_int, [ctxp, u64p, sz, C.POINTER(H)]),
     "zkg16_witness_free": (None, [ctxp, H]),
+    "zkg16_witness_read": (C.c_int, [ctxp, H, u64p, sz]),
     "zkg16_prove_resident": (C.c_int, [ctxp, H, H, H, u64p, u64p, u64p, u8p]),
     "zkg16_prove": (C.c_int, [ctxp, H, u64p, u64p] + [u64p, vp, vp] * 3 + [sz, sz, u64p, sz, u64p, u8p]),
     "zkg16_prove_partial": (C.c_int, [ctxp, H, H, H, u64p, u64p, u64p, u8p]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "zkg16_circuit_is_satisfied": (C.c_int, [vp]),
     "zkg16_circuit_export": (C.c_int, [vp, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3), u64p]),
     "zkg16_poseidon_hash": (C.c_int, [u64p, sz, u64p]),
+    "zkg16_witness_matrix": (C.c_int, [ctxp, sz, u64p, u64p, C.POINTER(H), vp, vp]),
+    "zkg16_matrix_sponge_states": (C.c_int, [sz, u64p, u64p, vp, u64p]),
     "zkg16_ntt": (C.c_int, [ctxp, u64p, sz, C.c_int, C.c_int]),
     "zkg16_msm_g1": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),
     "zkg16_msm_g2": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),

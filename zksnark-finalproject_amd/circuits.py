@@ -61,6 +61,21 @@ def matrix_witness(a, b, num_vars):
     return z
 
 
+def matrix_sponge_states(a, b):
+    """The host half of the device witness generator (zkg16_matrix_sponge_states; no GPU): the three native sponges of the
+    matrix handler with the state in front of every permutation -> (states [3, ceil(n^2/2), 3, 4], hashes [3, 4])."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    n = a.shape[0]
+    perms = (n * n + 1) // 2
+    states = np.zeros((3, perms, 3, 4), dtype=np.uint64)
+    hashes = np.zeros((3, 4), dtype=np.uint64)
+    rc = _lib.load().zkg16_matrix_sponge_states(n, a.reshape(-1), b.reshape(-1), states.ctypes.data, hashes.reshape(-1))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_matrix_sponge_states")
+    return states, hashes
+
+
 def fibonacci_circuit(a, b, steps):
     h = C.c_void_p()
     rc = _lib.load().zkg16_circuit_fibonacci(a, b, steps, C.byref(h))

@@ -1060,6 +1060,19 @@ int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n
     ZK_API_END(ctx)
 }
 
+// The assignment behind a witness handle, copied back to the host (tests compare the device-built MatrixCircuit assignment of
+// zkg16_witness_matrix with the host builder's byte for byte).
+int zkg16_witness_read(zkg16_ctx *ctx, uint64_t witness_handle, uint64_t *out, size_t n_assign) {
+    if (!out) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    WitnessDev *w = find_handle(ctx->wits, witness_handle);
+    if (!w) return ZKG16_ERR_BAD_HANDLE;
+    if (w->n != n_assign) return ZKG16_ERR_BAD_ARG;
+    ZK_HIP(hipMemcpyAsync(out, w->z.p, n_assign * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_API_END(ctx)
+}
+
 void zkg16_witness_free(zkg16_ctx *ctx, uint64_t h) {
     if (!ctx) return;
     std::lock_guard<std::mutex> lk(ctx->mu);

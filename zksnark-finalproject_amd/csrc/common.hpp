@@ -196,6 +196,7 @@ struct zkg16_ctx {
     int num_cus = 256;
     bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
     zk::FixedBaseCache fb_g1, fb_g2;
+    zk::DevBuf poseidon_dev;                          // Poseidon MDS + round constants, Montgomery form (witness.hip), uploaded on first use
 };
 
 namespace zk {

@@ -126,6 +126,25 @@ class Device:
         self._check(self.lib.zkg16_witness_load(self.ctx, z, z.shape[0], C.byref(handle)))
         return handle.value
 
+    def witness_matrix(self, a, b):
+        """The MatrixCircuit's assignment for (a, b) built on the device (zkg16_witness_matrix) ->
+        (witness handle, public inputs [3, 4] = hash_a, hash_b, hash_c, dict of ms: host sponges / device / whole call)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        n = a.shape[0]
+        if a.shape != (n, n) or b.shape != (n, n):
+            raise ValueError("witness_matrix: a and b must be n x n")
+        handle = C.c_uint64()
+        pub = np.zeros((3, 4), dtype=np.uint64)
+        ms = (C.c_float * 3)()
+        self._check(self.lib.zkg16_witness_matrix(self.ctx, n, a.reshape(-1), b.reshape(-1), C.byref(handle), pub.ctypes.data, C.addressof(ms)))
+        return handle.value, pub, dict(host_sponges_ms=float(ms[0]), device_ms=float(ms[1]), call_ms=float(ms[2]))
+
+    def witness_read(self, h, n_assign):
+        z = np.zeros((n_assign, 4), dtype=np.uint64)
+        self._check(self.lib.zkg16_witness_read(self.ctx, h, z.reshape(-1), n_assign))
+        return z
+
     def witness_free(self, h):
         self.lib.zkg16_witness_free(self.ctx, h)
 
@@ -164,7 +183,8 @@ class Device:
         d = _u64(data).reshape(-1, 4).copy()
         n = d.shape[0]
         log_n = n.bit_length() - 1
-        assert 1 << log_n == n
+        if 1 << log_n != n:
+            raise ValueError("ntt: length %d is not a power of two" % n)
         self._check(self.lib.zkg16_ntt(self.ctx, d, log_n, int(inverse), int(coset)))
         return d
 
@@ -274,7 +294,8 @@ def shard_plan(n_ranks, m_total, n_h, b_density=0.0, h_ranks=0, z_cost=None, win
     blind = np.zeros(n_ranks, dtype=np.uint8)
     k = C.c_int(0)
     zc = None if z_cost is None else np.ascontiguousarray(z_cost, dtype=np.float32)
-    assert zc is None or zc.shape[0] == m_total
+    if zc is not None and zc.shape[0] != m_total:
+        raise ValueError("shard_plan: z_cost has %d entries, m_total is %d" % (zc.shape[0], m_total))
     rc = lib.zkg16_shard_plan_tables(n_ranks, m_total, n_h, float(b_density), h_ranks, _ptr(zc), int(bool(window_tables)), ranges, blind, C.byref(k))
     if rc != 0:
         raise Zkg16Error(rc, lib.zkg16_strerror(rc).decode())
@@ -326,7 +347,8 @@ def verify(vk, public_inputs_mont, proof48, inf3):
     lib = _lib.load()
     gabc = _u64(vk["gamma_abc_g1"]).reshape(-1, 12)
     pub = _u64(public_inputs_mont).reshape(-1, 4)
-    assert pub.shape[0] == gabc.shape[0] - 1
+    if pub.shape[0] != gabc.shape[0] - 1:          # a real exception: the C side reads num_instance - 1 inputs
+        raise ValueError("verify: %d public inputs for a key with %d instance variables" % (pub.shape[0], gabc.shape[0]))
     ok = C.c_int(0)
     rc = lib.zkg16_verify(_u64(vk["alpha_g1"]), _u64(vk["beta_g2"]), _u64(vk["gamma_g2"]), _u64(vk["delta_g2"]), gabc, gabc.shape[0],
                           _ptr(pub) if pub.size else None, _u64(proof48), np.ascontiguousarray(inf3, dtype=np.uint8), C.byref(ok))
@@ -353,7 +375,8 @@ def pairing_check(g1_points, g2_points, g1_inf=None, g2_inf=None, plain_final_ex
     lib = _lib.load()
     g1 = _u64(g1_points).reshape(-1, 12)
     g2 = _u64(g2_points).reshape(-1, 24)
-    assert g1.shape[0] == g2.shape[0]
+    if g1.shape[0] != g2.shape[0]:
+        raise ValueError("pairing_check: %d G1 points against %d G2 points" % (g1.shape[0], g2.shape[0]))
     n = g1.shape[0]
     i1 = np.ascontiguousarray(g1_inf if g1_inf is not None else np.zeros(n), dtype=np.uint8)
     i2 = np.ascontiguousarray(g2_inf if g2_inf is not None else np.zeros(n), dtype=np.uint8)
@@ -408,7 +431,8 @@ def verify_prepared(pvk, public_inputs_mont, proof48, inf3):
     lib = _lib.load()
     gabc = _u64(pvk["gamma_abc_g1"]).reshape(-1, 12)
     pub = _u64(public_inputs_mont).reshape(-1, 4)
-    assert pub.shape[0] == gabc.shape[0] - 1
+    if pub.shape[0] != gabc.shape[0] - 1:
+        raise ValueError("verify_prepared: %d public inputs for a key with %d instance variables" % (pub.shape[0], gabc.shape[0]))
     g, d = _u64(pvk["gamma_neg_pc"]).reshape(-1, 36), _u64(pvk["delta_neg_pc"]).reshape(-1, 36)
     ok = C.c_int(0)
     rc = lib.zkg16_verify_prepared(gabc, gabc.shape[0], _ptr(pub) if pub.size else None, _u64(pvk["alpha_beta"]), g, d, g.shape[0],

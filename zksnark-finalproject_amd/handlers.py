@@ -127,15 +127,18 @@ def verify_proof(vk, public_inputs_mont, proof_b64):
     """Mirror of the verify handlers (matrix_proof.rs:183-205, fibbonaci_handler.rs:118-145): decode the base64 compressed
     proof (and key, when given as the base64 string the prove mirrors return), check the Groth16 equation with the host
     verifier (zkg16_verify) -> {valid, verifying_time}."""
+    from ._lib import Zkg16Error
     from .device import verify, verify_prepared
     t0 = time.perf_counter()
     try:
         if isinstance(vk, str):
             raw = __import__("base64").standard_b64decode(vk)
-            n = int.from_bytes(raw[336:344], "little")
+            n = int.from_bytes(raw[336:344], "little") if len(raw) >= 344 else 0
             vk = wire.pvk_deserialize_compressed(raw) if len(raw) > 344 + 48 * n else wire.vk_deserialize_compressed(raw)
         proof, inf = wire.decode_proof(proof_b64)
-    except ValueError:                  # the reference's decode_proof / decode_pvk return None and the handler answers invalid
+        ok = verify_prepared(vk, public_inputs_mont, proof, inf) if "alpha_beta" in vk else verify(vk, public_inputs_mont, proof, inf)
+    except (ValueError, IndexError, Zkg16Error):
+        # the reference's decode_proof / decode_pvk return None and the handler answers invalid; a key or input list of the
+        # wrong shape is the same answer, never an exception out of the handler
         return dict(valid=False, verifying_time=time.perf_counter() - t0)
-    ok = verify_prepared(vk, public_inputs_mont, proof, inf) if "alpha_beta" in vk else verify(vk, public_inputs_mont, proof, inf)
     return dict(valid=bool(ok), verifying_time=time.perf_counter() - t0)

@@ -180,13 +180,21 @@ def vk_serialize_compressed(vk):
     return out
 
 
+# Untrusted bytes: every length prefix is checked against the bytes that are actually there BEFORE anything is allocated
+# or indexed (a truncated or patched key must come back as ValueError, which the handlers answer with valid = False).
+_MAX_INSTANCE = 1 << 24
+
+
 def vk_deserialize_compressed(b):
+    if len(b) < 344:
+        raise ValueError("verifying key is truncated")
+    n = int.from_bytes(b[336:344], "little")
+    if n < 1 or n > _MAX_INSTANCE or len(b) != 344 + 48 * n:
+        raise ValueError("verifying key length does not match its gamma_abc_g1 count")
     a, _ = g1_decompress(b[:48])
     beta, _ = g2_decompress(b[48:144])
     gamma, _ = g2_decompress(b[144:240])
     delta, _ = g2_decompress(b[240:336])
-    n = int.from_bytes(b[336:344], "little")
-    assert len(b) == 344 + 48 * n
     gabc = np.array([g1_decompress(b[344 + 48 * i:392 + 48 * i])[0] for i in range(n)], dtype=np.uint64).reshape(n, 12)
     return dict(alpha_g1=a, beta_g2=beta, gamma_g2=gamma, delta_g2=delta, gamma_abc_g1=gabc)
 
@@ -231,15 +239,26 @@ def pvk_serialize_compressed(pvk):
             _prepared_bytes(pvk["gamma_neg_pc"]) + _prepared_bytes(pvk["delta_neg_pc"]))
 
 
+PVK_COEFFS = 68          # line-coefficient triples of a BLS12-381 G2Prepared (63 doublings + 5 additions of |z|)
+
+
 def pvk_deserialize_compressed(b):
+    if len(b) < 344:
+        raise ValueError("prepared verifying key is truncated")
     n = int.from_bytes(b[336:344], "little")
+    if n < 1 or n > _MAX_INSTANCE:
+        raise ValueError("prepared verifying key: implausible gamma_abc_g1 count")
     off = 344 + 48 * n
+    if len(b) != off + 576 + 2 * (8 + 288 * PVK_COEFFS + 1):
+        raise ValueError("prepared verifying key length does not match its counts")
     pvk = vk_deserialize_compressed(b[:off])
     pvk["alpha_beta"] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(12)])
     off += 576
     for name in ("gamma_neg_pc", "delta_neg_pc"):
         m = int.from_bytes(b[off:off + 8], "little")
         off += 8
+        if m != PVK_COEFFS or off + 288 * m + 1 > len(b):
+            raise ValueError("G2Prepared coefficient count is not %d" % PVK_COEFFS)
         rows = np.zeros((m, 36), dtype=np.uint64)
         for i in range(m):
             rows[i] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(6)])
