@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--matrix-n", type=int, default=128, help="n of the n x n matrix-mul circuit (128 = largest single-GPU config, 2^24 domain)")
     ap.add_argument("--workload", default="matrix", choices=["matrix", "prime"],
                     help="matrix = the reference's MatrixCircuit (metric workload); prime = the reference's PrimeCircuit (configs[4])")
-    ap.add_argument("--legs", default="46,32", help="N = 1: further matrix sizes measured after the timed region (comma list, '' = none)")
+    ap.add_argument("--legs", default="46,32,prime,fib1000",
+                    help="N = 1: further workloads measured after the timed region (comma list, '' = none): a number = that matrix size; "
+                         "prime = the reference's PrimeCircuit (BASELINE configs[4]); fibN = FibonacciCircuit with N rounds (configs[0])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host synthesis + host-pointer prove) leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (rehearsal: several ranks on one GPU)")
@@ -65,8 +67,10 @@ def parse():
     ap.add_argument("--h-ranks", type=int, default=0, help="N > 1, shard: ranks that run the witness map (0 = cost model; N = equal split)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="N = 1: after the timed region, also report throughput with this many proofs in flight (one ctx per host thread)")
-    ap.add_argument("--no-replicas-leg", action="store_true",
-                    help="N > 1, shard: skip the extra leg that times every rank proving its own proofs on the whole key (weak scaling)")
+    ap.add_argument("--replicas-leg", action="store_true",
+                    help="N > 1, shard: after the timed sharded region also time every rank proving its own proofs on the whole key (weak "
+                         "scaling; keeps the whole key + its tables on every rank, so off by default: the timed leg must not be lost to it)")
+    ap.add_argument("--no-replicas-leg", action="store_true", help="(default since round 3; accepted for older command lines)")
     ap.add_argument("--tables", default="auto", choices=["auto", "on", "off"],
                     help="auto = window tables for the resident key (zkg16_pk_precompute; the plain key is timed first and reported "
                          "beside it); on = the same without the plain-key proofs (profiling runs); off = plain key only")
@@ -106,7 +110,13 @@ def draw_key_inputs(seed):
 def synthesize(workload, n, x=None):
     """-> (SynthesizedCircuit, seconds, description).  matrix: all-ones n x n inputs as bench/matrix.py:11."""
     t0 = time.perf_counter()
-    if workload == "prime":
+    if workload.startswith("fib"):
+        from zksnark_finalproject_amd.circuits import fibonacci_circuit
+        rounds = int(workload[3:] or n)
+        circ = fibonacci_circuit(0, 1, rounds)           # bench/fibo.py:26-34: a = 0, b = 1
+        desc = ("FibonacciCircuit mirror, %d rounds (BASELINE configs[0]): %d constraints, %d witness vars, domain 2^%d"
+                % (rounds, circ.num_constraints, circ.num_witness, circ.domain.bit_length() - 1))
+    elif workload == "prime":
         from zksnark_finalproject_amd.circuits import prime_circuit
         circ = prime_circuit(0x123456789ABCDEF if x is None else x, 32)
         desc = ("Fermat-prime circuit (PrimeCircuit mirror, BASELINE configs[4]: SHA-256 + 3 Fermat bases, 20-bit modpow): %d constraints, "
@@ -121,20 +131,22 @@ def synthesize(workload, n, x=None):
 
 
 def profile_lookup(key):
-    """Numbers that come from committed profile summaries (profiles/bench_constants_r2.json, written by tools/pmc_to_json.py from
-    the rocprofv3 --pmc / microbench logs next to it); None when the summary has no entry for this configuration."""
-    path = os.path.join(ROOT, "profiles", "bench_constants_r2.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
-        return None
-    cur = d
-    for k in key:
-        if not isinstance(cur, dict) or k not in cur:
-            return None
-        cur = cur[k]
-    return cur
+    """Numbers that come from committed profile summaries (profiles/bench_constants_r3.json, else _r2: written by
+    tools/pmc_to_json.py from the rocprofv3 --pmc / microbench logs next to it); None when no summary has the entry."""
+    for name in ("bench_constants_r3.json", "bench_constants_r2.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                cur = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k in key:
+            if not isinstance(cur, dict) or k not in cur:
+                cur = None
+                break
+            cur = cur[k]
+        if cur is not None:
+            return cur
+    return None
 
 
 def cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs, headline_nc):
@@ -229,33 +241,39 @@ def main():
         z_lo, z_hi, h_lo, h_hi, blind = plan[rank]
         full = ph
         ph = dev.pk_slice(full, z_lo, z_hi, h_lo, h_hi, blind)      # device-to-device
-        if args.no_replicas_leg:
+        if not args.replicas_leg:
             dev.pk_free(full)                                       # the whole key is dropped again
             full = None
     wh = dev.witness_load(circ.z)
     rng = np.random.default_rng(99)
     rs = [(fr_mont(int.from_bytes(rng.bytes(31), "little")), fr_mont(int.from_bytes(rng.bytes(31), "little"))) for _ in range(args.steps + args.warmup + 2)]
 
-    def with_tables(d, pk_h, prove_once):
+    def with_tables(d, pk_h, prove_once, plain_steps=0):
         """Window tables for a key that stays resident; the plain key is timed first (a few proofs) so both appear in the line."""
         if args.tables == "off":
             return None
-        plain_ms = None
+        plain_ms, plain = None, None
         if prove_once is not None and args.tables == "auto":
-            prove_once()
-            k = 3
+            for _ in range(max(1, min(args.warmup, 2))):
+                prove_once()
+            k = max(3, plain_steps)
+            torch.cuda.synchronize()
             t_ = time.perf_counter()
             for _ in range(k):
                 prove_once()
+            torch.cuda.synchronize()
             plain_ms = (time.perf_counter() - t_) / k * 1e3
+            plain = {"ms_per_step": plain_ms, "value": 1e3 / plain_ms, "unit": "proofs/s", "steps": k,
+                     "note": "the key as the reference's per-request setup produces it (no window tables): the like-for-like figure"}
         t_ = time.perf_counter()
         added = d.pk_precompute(pk_h)
         pre_s = time.perf_counter() - t_
         bz, bh = d.pk_table_bits(pk_h)
         return {"window_bits_z": bz, "window_bits_h": bh, "table_bytes": added, "precompute_s": pre_s, "plain_key_ms_per_proof": plain_ms,
+                "plain_key": plain,
                 "note": "zkg16_pk_precompute: 2^(c w) multiples of every base kept in HBM, all digits of a scalar in one bucket set per MSM; "
                         "same proofs bit for bit (tests/test_gpu_parity.py::test_window_tables_*); built once per resident key"}
-    tables_info = with_tables(dev, ph, (lambda: dev.prove_resident(ph, rh, wh, *rs[0])) if world == 1 else None)
+    tables_info = with_tables(dev, ph, (lambda: dev.prove_resident(ph, rh, wh, *rs[0])) if world == 1 else None, plain_steps=args.steps)
 
     xdev = "cuda" if on_gpu else "cpu"
     if sharded:
@@ -291,7 +309,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dev.kernel_timing(False)
+    per_rank = None
     if world > 1:
+        # every rank's own time of the timed region, so that the curve can be read against the per-shard predictions
+        # (profiles/shard_timing_r2b.txt): the witness-map ranks are expected to be the floor
+        mine = torch.tensor([dt], dtype=torch.float64, device=xdev)
+        allt = [torch.empty(1, dtype=torch.float64, device=xdev) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [float(x.item()) / args.steps * 1e3 for x in allt]
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -307,6 +332,9 @@ def main():
     acc = dev.kernel_stats("msm_accumulate_g1")
     acc2 = dev.kernel_stats("msm_accumulate_g2")
 
+    tabled = bool(tables_info and (tables_info["window_bits_z"] or tables_info["window_bits_h"]))
+    cfg_key = ("n%d" % args.matrix_n if args.workload == "matrix" else args.workload) + ("_tables" if tabled else "")
+    acc_waves = dev.last_acc_waves()
     extra_out = {}
     if rank == 0 and world == 1:
         # ---- stand-alone witness map and one transform of the workload's domain (second kernel family of the path)
@@ -317,7 +345,7 @@ def main():
             gbs = 64.0 * shp["domain"] / (ntt_ms * 1e-3) / 1e9
             extra_out["roofline_ntt"] = {"bound": "hbm", "kernel": "ntt_pass_cols_u + ntt_pass_rows_u (one coset-inverse transform of 2^%d)" % log_n,
                                          "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "ms": ntt_ms, "transforms_per_proof": 7,
-                                         "traffic": profile_lookup(["n%d" % args.matrix_n, "ntt_transform_traffic_bytes"]),      # the transforms do not depend on the key's tables
+                                         "traffic": profile_lookup([cfg_key, "ntt_transform_traffic_bytes"]),      # same profile run as roofline.traffic
                                          "note": "64 algorithmic bytes per element (read once, written once); integer-ALU bound too"}
             extra_out["witness_map_standalone_ms"] = dev.bench_witness_map(rh, wh, 3)
         except Exception as e:      # noqa: BLE001 - an extra leg must never cost the contract line
@@ -340,20 +368,40 @@ def main():
                 ok2 = verify(vk, c2.public_inputs, p2, i2)
                 e2e = {"seconds": t3 - t1, "proofs_per_sec": 1.0 / (t3 - t1), "constraints_per_sec": shp["nc"] / (t3 - t1),
                        "host_synthesis_s": t2 - t1, "prove_host_pointers_s": t3 - t2, "first_request_s": first, "proof_verified": bool(ok2),
+                       "what": "the full first-request path: matrices + assignment synthesized on the host, everything uploaded inside zkg16_prove",
                        "note": "host synthesis (C++ mirror, full R1CS + assignment) + zkg16_prove with host pointers (matrices and "
                                "assignment uploaded over PCIe inside the call); the key stays resident, as the reference holds its pk"}
                 if args.workload == "matrix":
-                    # a server that kept the matrices of this size (they depend on n alone): assignment only + resident prove
-                    from zksnark_finalproject_amd.circuits import matrix_witness
+                    # a server that kept the matrices of this size (they depend on n alone).  Per request only the assignment:
+                    # built ON THE DEVICE from the host sponges' entering states (zkg16_witness_matrix), then the resident proof
                     ones = np.ones((args.matrix_n, args.matrix_n), dtype=np.uint64)
+                    best = None
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        w2, pub2, wms = dev.witness_matrix(ones, ones)
+                        t2 = time.perf_counter()
+                        p3, i3 = dev.prove_resident(ph, rh, w2, r, s)
+                        t3 = time.perf_counter()
+                        dev.witness_free(w2)
+                        if best is None or t3 - t1 < best[0]:
+                            best = (t3 - t1, t2 - t1, t3 - t2, wms)
+                    e2e["cached_matrices"] = {"seconds": best[0], "proofs_per_sec": 1.0 / best[0], "constraints_per_sec": shp["nc"] / best[0],
+                                              "assignment_on_device_s": best[1], "host_sponges_ms": best[3]["host_sponges_ms"],
+                                              "assignment_kernels_ms": best[3]["device_ms"], "prove_resident_s": best[2],
+                                              "same_proof": bool(np.array_equal(p3, p2)), "public_inputs_match": bool(np.array_equal(pub2, c2.public_inputs)),
+                                              "note": "best of 3: zkg16_witness_matrix (three native Poseidon sponges on three host threads -> per-"
+                                                      "permutation entering states -> device kernels write z in place) + zkg16_prove_resident on the "
+                                                      "matrices kept per size; the sponges are sequential by construction (hasher.rs:17-27)"}
+                    # the round-2 form of the same request, for comparison: assignment built on the host, uploaded over PCIe
+                    from zksnark_finalproject_amd.circuits import matrix_witness
                     t1 = time.perf_counter()
                     z2 = matrix_witness(ones, ones, shp["num_vars"])
                     w2 = dev.witness_load(z2)
-                    p3, i3 = dev.prove_resident(ph, rh, w2, r, s)
+                    p4, i4 = dev.prove_resident(ph, rh, w2, r, s)
                     t2 = time.perf_counter()
                     dev.witness_free(w2)
-                    e2e["cached_matrices"] = {"seconds": t2 - t1, "proofs_per_sec": 1.0 / (t2 - t1), "same_proof": bool(np.array_equal(p3, p2)),
-                                              "note": "assignment-only synthesis + upload + zkg16_prove_resident on the matrices kept per size"}
+                    e2e["cached_matrices_host_assignment"] = {"seconds": t2 - t1, "same_proof": bool(np.array_equal(p4, p2))}
+                    del z2
                 del c2
                 extra_out["end_to_end"] = e2e
             except Exception as e:      # noqa: BLE001
@@ -362,7 +410,7 @@ def main():
     # ---- N > 1, shard: the same ranks as independent provers (every rank its own proofs on the whole key, no exchange) — the
     # throughput a server farm would get from N GPUs, beside the one-proof latency the sharded path is about
     replicas = None
-    if sharded and not args.no_replicas_leg and full is not None:
+    if sharded and args.replicas_leg and full is not None:
         k_r = max(2, min(args.steps, 5))
         dt_r, ok_r, err_r = float("inf"), False, None
         barrier()
@@ -432,17 +480,18 @@ def main():
     legs = []
     gpu_proof_n32 = None
     if rank == 0 and world == 1 and args.workload == "matrix":
-        for n in [int(x) for x in args.legs.split(",") if x.strip()]:
+        for leg in [x.strip() for x in args.legs.split(",") if x.strip()]:
             try:
-                c, syn, d_ = synthesize("matrix", n)
+                wl, n = ("matrix", int(leg)) if leg.isdigit() else (leg, 0)
+                c, syn, d_ = synthesize(wl, n)
                 r_h = dev.r1cs_load(c.r1cs, c.num_vars)
                 t1 = time.perf_counter()
                 p_h, v_k = dev.setup_resident(r_h, c.num_instance, trap, g1, g2)
                 set_s = time.perf_counter() - t1
                 w_h = dev.witness_load(c.z)
-                leg_tables = with_tables(dev, p_h, lambda: dev.prove_resident(p_h, r_h, w_h, *rs[0]))
-                dev.prove_resident(p_h, r_h, w_h, *rs[0])
                 k = max(3, min(args.steps, 20))
+                leg_tables = with_tables(dev, p_h, lambda: dev.prove_resident(p_h, r_h, w_h, *rs[0]), plain_steps=k)
+                dev.prove_resident(p_h, r_h, w_h, *rs[0])
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for j in range(k):
@@ -450,16 +499,34 @@ def main():
                 torch.cuda.synchronize()
                 d1 = (time.perf_counter() - t1) / k
                 pr, pi = dev.prove_resident(p_h, r_h, w_h, *rs[-1])
-                if n == 32:
+                if wl == "matrix" and n == 32:
                     gpu_proof_n32 = (pr, pi)
-                legs.append({"workload": d_, "n": n, "ms_per_step": d1 * 1e3, "value": 1.0 / d1, "unit": "proofs/s", "steps": k,
-                             "constraints_per_sec": c.num_constraints / d1, "proof_verified": bool(verify(v_k, c.public_inputs, pr, pi)),
-                             "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings(),
-                             "window_tables": leg_tables})
-                for f, h in ((dev.pk_free, p_h), (dev.witness_free, w_h), (dev.r1cs_free, r_h)):
+                rec = {"workload": d_, "n": n if wl == "matrix" else leg, "ms_per_step": d1 * 1e3, "value": 1.0 / d1, "unit": "proofs/s", "steps": k,
+                       "constraints_per_sec": c.num_constraints / d1, "proof_verified": bool(verify(v_k, c.public_inputs, pr, pi)),
+                       "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings(),
+                       "window_tables": leg_tables}
+                for f, h in ((dev.pk_free, p_h), (dev.witness_free, w_h)):
                     f(h)
+                if wl != "matrix" and not args.no_cpu_baseline:
+                    # the CPU oracle proves these in seconds: same key (same trapdoor, through the host this time), same r, s ->
+                    # the proof bytes must be equal
+                    try:
+                        sys.path[:0] = [os.path.join(ROOT, "oracle")]
+                        import oracle as orc
+                        pk_host, _ = dev.setup(r_h, c.num_instance, c.num_vars, c.domain, trap, g1, g2)
+                        orc.set_threads(min(os.cpu_count() or 1, 16))
+                        t1 = time.perf_counter()
+                        op, oi = orc.prove(pk_host, rs[-1][0], rs[-1][1], c.r1cs, c.z)
+                        rec["oracle_seconds"] = time.perf_counter() - t1
+                        rec["oracle_match"] = bool(np.array_equal(op, pr) and np.array_equal(oi, pi))
+                        del pk_host
+                    except Exception as e:      # noqa: BLE001
+                        rec["oracle_match"] = None
+                        rec["oracle_error"] = repr(e)
+                dev.r1cs_free(r_h)
+                legs.append(rec)
             except Exception as e:      # noqa: BLE001
-                legs.append({"n": n, "error": repr(e)})
+                legs.append({"n": leg, "error": repr(e)})
 
     if rank == 0:
         total_proofs = args.steps * (world if (world > 1 and not sharded) else 1)
@@ -470,8 +537,6 @@ def main():
         alg_bytes = 128.0 * terms_per_launch
         avg_ms = acc["ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        tabled = bool(tables_info and (tables_info["window_bits_z"] or tables_info["window_bits_h"]))
-        cfg_key = ("n%d" % args.matrix_n if args.workload == "matrix" else args.workload) + ("_tables" if tabled else "")
         traffic = profile_lookup([cfg_key, "msm_accumulate_g1_traffic_bytes"]) if world == 1 else None
         out = {
             "metric": "groth16_proofs_per_sec", "value": total_proofs / dt, "unit": "proofs/s",
@@ -493,12 +558,18 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
                          "terms_per_launch": terms_per_launch,
-                         "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (~3,700 "
+                         "note": "integer-ALU bound by construction: one XYZZ mixed addition = 8 products + 2 squarings in Fq (3,542 "
                                  "v_mad_u64_u32) per window per 128 algorithmic bytes; traffic = PMC FETCH+WRITE of the same command from "
                                  "profiles/ (one 96-byte base or table entry gathered per (scalar, window) term); g2 accumulate avg %.3f ms" % (acc2["ms"] / max(acc2["launches"], 1))},
         }
         if plan is not None:
-            out["config"]["shard_plan"] = [{"rank": i, "z": [p[0], p[1]], "h": [p[2], p[3]], "blinding": p[4]} for i, p in enumerate(plan)]
+            out["config"]["shard_plan"] = [{"rank": i, "z": [p[0], p[1]], "h": [p[2], p[3]], "blinding": p[4],
+                                            "role": ("witness map + h share" if p[3] > p[2] else "") + (" + " if p[3] > p[2] and p[1] > p[0] else "") +
+                                                    ("z share" if p[1] > p[0] else ""),
+                                            "ms_per_step": per_rank[i] if per_rank else None} for i, p in enumerate(plan)]
+        if per_rank:
+            out["per_rank_ms_per_step"] = per_rank
+            out["slowest_rank"] = int(np.argmax(per_rank))
         # the bound that does apply: mixed additions per second against the same addition in a bare register-resident loop
         nshard = world if sharded else 1
         if world == 1:
@@ -519,14 +590,29 @@ def main():
             zc, bc, hc = term_counts
             exact = (2 * zc + (bc if bc else zc) + hc) / 4.0
             gadd = exact / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
+            # the bare register-resident loop at the occupancy the launches actually used (waves per SIMD read back from the plans;
+            # launches at different occupancies are weighted by their additions), and the multiplier's own bound beside it
+            by_waves = profile_lookup(["alu", "madd_g1_bare_gadd_per_s_by_waves"]) or {}
+            lists = [(zc, acc_waves[0], 2.0), ((bc if bc else zc), acc_waves[1] if bc else acc_waves[0], 1.0), (hc, acc_waves[2], 1.0)]
+            wsum = sum(cnt * mult for cnt, _, mult in lists)
+            peak = None
+            if by_waves and wsum > 0 and all(str(w) in by_waves for cnt, w, _ in lists if cnt):
+                # time-weighted (harmonic) mean of the bare rates: total additions / sum of (additions / rate)
+                peak = wsum / sum(cnt * mult / by_waves[str(w)] for cnt, w, mult in lists if cnt)
+            if peak is None:
+                peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
+            mad_bound = profile_lookup(["alu", "mad_bound_gadd_per_s"])
             out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": peak, "unit": "G mixed additions/s",
                           "frac": (gadd / peak) if peak else None,
+                          "waves_per_simd": {"z": acc_waves[0], "b": acc_waves[1], "h": acc_waves[2]},
+                          "mad_bound": mad_bound, "frac_of_mad_bound": (gadd / mad_bound) if mad_bound else None,
                           "additions_per_launch": exact, "term_lists": {"z": zc, "b": bc, "h": hc}, "additions_per_launch_estimate": est,
                           "note": "additions = lengths of the sorted term lists of the last proof, read back from the device "
                                   "(zkg16_last_term_counts): A and L walk the z list, B1 the B list, H the h list; peak = the same XYZZ "
-                                  "mixed addition in a bare register-resident loop at the kernel's occupancy (tools/microbench.hip; "
-                                  "profiles/bench_constants_r2.json names the log)"}
+                                  "mixed addition in a bare register-resident loop at the occupancy the launches used (zkg16_last_acc_waves; "
+                                  "tools/microbench.hip, the log is named in profiles/bench_constants_r3.json); mad_bound = the measured "
+                                  "v_mad_u64_u32 issue rate of the whole chip / 3,542 multiply-adds per mixed addition: the hardware bound "
+                                  "of this formula, which the bare loop itself reaches to ~80 %"}
         out.update(extra_out)
         out["window_tables"] = tables_info
         if replicas:

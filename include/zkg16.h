@@ -272,13 +272,19 @@ ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t 
                     uint64_t *out_affine, uint8_t *out_inf);
 
 /* ---- instrumentation --------------------------------------------------------------------------- */
-/* Per-stage device time of the last prove on this ctx (hipEvent pairs on the ctx stream), in ms:
- * [0] spmv, [1] ntt+pointwise, [2] msm digits+sort, [3] msm H, [4] msm L, [5] msm A, [6] msm B1, [7] msm B2,
- * [8] host tail, [9] total wall.  Returns the number of entries written. */
+/* Times of the last prove on this ctx, in ms (returns the number of entries written, up to 20):
+ * [0] unused, [1] witness map (device; upstream span "R1CS to QAP witness map"), [2] scalar digits + bucket scatter of both scalar
+ * vectors (device), [3..7] host-observed completion gaps of H, L, A, B1, B2 in collection order (NOT a breakdown: the first gap
+ * holds most of the device time), [8] host tail ("Finish C"), [9] total wall;
+ * [10..14] device time of the bucket accumulation + fix-ups of H, L, A, B1, B2 and [15..19] of their bucket reductions, from event
+ * pairs on the streams they ran on: upstream's "Compute C" = H + L, "Compute A", "Compute B in G1", "Compute B in G2"
+ * (ark-groth16 prover.rs).  MSMs overlap each other and the witness map, so the device times sum to more than [9]. */
 ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
 /* Lengths of the sorted (scalar, window) term lists of the last proof on this ctx = mixed additions of each MSM that walks the list:
  * [0] the z list (A and L), [1] the B list (B1 and B2; 0 = they used the z list), [2] the h list.  Synchronises the ctx. */
 ZKG16_API int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]);
+/* G1 accumulation waves per SIMD (2 or 4) the last proof's term lists ran at: [0] z list, [1] B list, [2] h list; 0 = not built. */
+ZKG16_API int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]);
 /* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0 off, 1 every kernel family, 2 only the
  * bucket-accumulation launches (five event pairs per proof instead of ~60).  stats are accumulated per kernel name since
  * the last reset. */

@@ -780,7 +780,8 @@ def test_proof_from_device_witness_equals_proof_from_host_witness(dev, oracle, n
     b = rng_np.integers(0, 1 << 40, size=(n, n), dtype=np.uint64)
     circ = matrix_circuit(a, b)
     rng = random.Random(11 * n)
-    pk, _ = synth.make_pk(oracle, circ.r1cs, circ.num_witness, rng, point_gen=dev.fixed_base)
+    oracle.set_threads(min(os.cpu_count() or 1, 16))
+    pk, _ = synth.make_pk(oracle, circ.r1cs, circ.num_vars, rng, point_gen=dev.fixed_base)
     r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
     ph = dev.pk_load(pk, circ.num_instance)
     rh = dev.r1cs_load(circ.r1cs, circ.num_vars)

@@ -21,4 +21,4 @@ for name, circ in (("fibonacci 186 rounds", fibonacci_circuit(0, 1, 186)), ("fib
         dev.prove_resident(ph, rh, wh, r, s)
     dt = (time.perf_counter() - t0) / 20
     print("%s: %d constraints, domain 2^%d: %.3f ms/proof; stages %s" % (name, circ.num_constraints, circ.domain.bit_length() - 1, dt * 1e3,
-          {k: round(v, 3) for k, v in dev.last_timings().items()}), flush=True)
+          {k: round(v, 3) for k, v in dev.last_timings().items() if isinstance(v, float)}), flush=True)

@@ -29,7 +29,7 @@ ap.add_argument("--fetch")
 ap.add_argument("--write")
 ap.add_argument("--microbench")
 ap.add_argument("--note", default="")
-ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "bench_constants_r2.json"))
+ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "bench_constants_r3.json"))
 a = ap.parse_args()
 d = json.load(open(a.out)) if os.path.exists(a.out) else {}
 if a.fetch and a.write:
@@ -49,12 +49,20 @@ if a.fetch and a.write:
                                         if f.get(k, 0.0) + w.get(k, 0.0) > 1e6}
     e["source"] = {"fetch_csv": os.path.relpath(a.fetch, ROOT), "write_csv": os.path.relpath(a.write, ROOT), "note": a.note}
 if a.microbench:
-    best = 0.0
+    by_waves, mad = {}, 0.0
     for line in open(a.microbench):
         m = re.match(r"madd G1 \(64thr blk\)\s+blocks/CU=(\d+)\s+[\d.]+ ms\s+([\d.]+) Gop/s", line)
-        if m and int(m.group(1)) == 8:           # 8 blocks of 64 threads per CU = 2 waves per SIMD, the kernel's occupancy
-            best = float(m.group(2))
-    d.setdefault("alu", {})["madd_g1_bare_gadd_per_s"] = best
-    d["alu"]["source"] = os.path.relpath(a.microbench, ROOT) + " (row 'madd G1 (64thr blk) blocks/CU=8')"
+        if m and int(m.group(1)) % 4 == 0:      # b blocks of 64 threads per CU = b / 4 waves per SIMD
+            by_waves[str(int(m.group(1)) // 4)] = float(m.group(2))
+        m = re.match(r"v_mad_u64_u32\s+blocks/CU=\d+\s+[\d.]+ ms\s+([\d.]+) Gop/s", line)
+        if m:
+            mad = max(mad, float(m.group(1)))
+    alu = d.setdefault("alu", {})
+    alu["madd_g1_bare_gadd_per_s_by_waves"] = by_waves          # the kernel's occupancy is read back per launch (zkg16_last_acc_waves)
+    alu["madd_g1_bare_gadd_per_s"] = by_waves.get("2", 0.0)
+    alu["v_mad_u64_u32_gop_per_s"] = mad                        # best measured issue rate of the whole chip (cycles/instr x held clock)
+    alu["mads_per_mixed_addition"] = 3542
+    alu["mad_bound_gadd_per_s"] = mad / 3542.0
+    alu["source"] = os.path.relpath(a.microbench, ROOT) + " (rows 'madd G1 (64thr blk) blocks/CU=4w' and the best 'v_mad_u64_u32' row)"
 json.dump(d, open(a.out, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: (v if k == "alu" else {x: y for x, y in v.items() if x != "per_kernel_bytes_per_launch"}) for k, v in d.items()}, indent=1))

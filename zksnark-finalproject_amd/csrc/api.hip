@@ -242,6 +242,21 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     if (pk.n_h_total != N - 1) throw HipError{hipErrorInvalidValue, "prove: h_query length != N-1", __FILE__, __LINE__};
     EventSet evs;                         // 0-1: z-side sort (main stream), 2-4: witness map / h-side sort (aux stream)
     hipEvent_t *ev = evs.ev;
+    // A throw between the first enqueue and the last collect (e.g. out of memory in a slot's bucket array) must not leave
+    // kernels of this proof in flight: the next proof on the ctx rewrites extra_host and reuses the workspaces and slots.
+    struct DrainOnError {
+        zkg16_ctx *c;
+        bool ok = false;
+        ~DrainOnError() {
+            if (ok) return;
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->wm_stream);
+            for (auto &sl : c->slots) {
+                if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+                sl.active = sl.pending_reduce = sl.fixups_pending = sl.last_of_proof = false;
+            }
+        }
+    } drain{ctx};
     const double t0 = now_ms();
 
     // ---- main stream: the z-side scalar vector (z-slice || r, s, -rs), read in place by the digit kernel -> digits -> sort.
@@ -379,7 +394,23 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     lap(3);
     float ms;
     // [1] witness map, [2] digits+sort of both vectors (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2
-    // (collected in the order B2, L, A, B1, H — the first gap contains most of the device time)
+    // (collected in the order B2, L, A, B1, H — the first gap contains most of the device time: NOT a breakdown);
+    // [10..14] device time of the bucket accumulation (+ fix-ups) of H, L, A, B1, B2, [15..19] of their bucket reductions, from
+    // event pairs on the streams they ran on — the per-stage times upstream's spans ("Compute C" = H + L, "Compute A",
+    // "Compute B in G1", "Compute B in G2": ark-groth16 prover.rs) correspond to.  Kernels of different MSMs overlap, so these
+    // sum to more than the proof.
+    {
+        const int slot_of[5] = {1, 2, 3, 4, 0};     // H, L, A, B1, B2
+        for (int k = 0; k < 5; k++) {
+            MsmSlot &sl = ctx->slots[slot_of[k]];
+            const bool ran = k == 0 ? nh > 0 : z_side;
+            float acc_ms = 0, red_ms = 0;
+            if (ran && sl.acc_start && hipEventElapsedTime(&acc_ms, sl.acc_start, sl.acc_done) != hipSuccess) { acc_ms = 0; (void)hipGetLastError(); }
+            if (ran && sl.red_start && hipEventElapsedTime(&red_ms, sl.red_start, sl.red_done) != hipSuccess) { red_ms = 0; (void)hipGetLastError(); }
+            ctx->timings[10 + k] = acc_ms;
+            ctx->timings[15 + k] = red_ms;
+        }
+    }
     ctx->timings[0] = 0;
     ZK_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
     ctx->timings[1] = ms;
@@ -388,6 +419,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     ZK_HIP(hipEventElapsedTime(&ms, ev[3], ev[4]));
     ctx->timings[2] += ms;
     ctx->timings[9] = (float)(now_ms() - t0);
+    drain.ok = true;
 }
 
 // Host tail (a9): A = alpha + MSM_a, B = beta + MSM_b, C = s*A + r*B1 + MSM_l + MSM_h.
@@ -460,10 +492,11 @@ int r1cs_create(const uint64_t *const rp[3], const uint32_t *const col[3], const
             for (size_t k = k0; k < k1; k++) top = col[i][k] > top ? col[i][k] : top;
             if (k1 > k0 && top >= num_variables) bad[t] = 1;
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; t++) th.emplace_back(scan, t);
-        scan(0);
-        for (auto &x : th) x.join();
+        {
+            ThreadGroup tg;
+            for (int t = 1; t < T; t++) tg.run([&scan, t]() { scan(t); });
+            scan(0);
+        }
         for (int t = 0; t < T; t++)
             if (bad[t]) return ZKG16_ERR_BAD_ARG;
         r->nnz[i] = nnz;
@@ -496,14 +529,15 @@ void upload_h2d(zkg16_ctx *ctx, void *dst, const void *src, size_t bytes) {
         ZK_HIP(hipEventSynchronize(ctx->stage_done[slot]));         // the copy that last used this half has left it (a fresh event is complete)
         unsigned char *stage = static_cast<unsigned char *>(ctx->stage_host[slot]);
         constexpr int T = 4;
-        std::thread th[T - 1];
         const size_t part = (len / T + 4095) & ~(size_t)4095;
-        for (int t = 1; t < T; t++) {
-            const size_t lo = part * t < len ? part * t : len, hi = part * (t + 1) < len ? part * (t + 1) : len;
-            th[t - 1] = std::thread([=]() { if (hi > lo) memcpy(stage + lo, s + off + lo, hi - lo); });
+        {
+            ThreadGroup tg;
+            for (int t = 1; t < T; t++) {
+                const size_t lo = part * t < len ? part * t : len, hi = part * (t + 1) < len ? part * (t + 1) : len;
+                tg.run([=]() { if (hi > lo) memcpy(stage + lo, s + off + lo, hi - lo); });
+            }
+            memcpy(stage, s + off, part < len ? part : len);
         }
-        memcpy(stage, s + off, part < len ? part : len);
-        for (auto &x : th) x.join();
         ZK_HIP(hipMemcpyAsync(d + off, stage, len, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipEventRecord(ctx->stage_done[slot], ctx->stream));
     }
@@ -624,6 +658,8 @@ void zkg16_destroy(zkg16_ctx *ctx) {
         if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
         if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
         if (sl.red_done) (void)hipEventDestroy(sl.red_done);
+        if (sl.acc_start) (void)hipEventDestroy(sl.acc_start);
+        if (sl.red_start) (void)hipEventDestroy(sl.red_start);
         sl.buckets.release();
         sl.wsums_dev.release();
         sl.seg_head.release();
@@ -1394,7 +1430,7 @@ int zkg16_fixed_base_g2(zkg16_ctx *ctx, const uint64_t base[24], const uint64_t 
 int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap) {
     if (!ctx || !ms) return 0;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    const int n = cap < 10 ? cap : 10;
+    const int n = cap < 20 ? cap : 20;
     for (int i = 0; i < n; i++) ms[i] = ctx->timings[i];
     return n;
 }
@@ -1413,6 +1449,16 @@ int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]) {
         counts[i] = v;
     }
     ZK_API_END(ctx)
+}
+
+// G1 accumulation waves per SIMD of the last proof's three term lists (z, B, h; 0 = list not built): the occupancy the
+// bucket accumulations actually ran at, which is the row of the bare-loop microbenchmark bench.py must compare them with.
+int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]) {
+    if (!ctx || !waves) return ZKG16_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MsmWorkspace *w[3] = {&ctx->ws_z, &ctx->ws_zb, &ctx->ws_h};
+    for (int i = 0; i < 3; i++) waves[i] = w[i]->last_tb ? (int)(w[i]->last_lanes_g1 / ((uint32_t)ctx->num_cus * 4u * 64u)) : 0;
+    return ZKG16_OK;
 }
 
 int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {

@@ -9,6 +9,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkg16.h"
@@ -37,6 +39,31 @@ struct HipError {
 void *dev_acquire(size_t bytes, size_t *got);      // api.hip; throws HipError
 void dev_release(void *p, size_t bytes) noexcept;
 void dev_cache_flush() noexcept;
+
+// Helper threads of one host-side job.  A std::thread that goes out of scope while joinable calls std::terminate, and the
+// constructor itself can throw (EAGAIN): behind a C ABI neither may take the process down.  run() starts fn on a new thread,
+// or — when none can be started — runs it right here; the destructor joins whatever was started, on every exit path.
+class ThreadGroup {
+    std::vector<std::thread> th_;
+  public:
+    ThreadGroup() = default;
+    ThreadGroup(const ThreadGroup &) = delete;
+    ThreadGroup &operator=(const ThreadGroup &) = delete;
+    template <class Fn>
+    void run(Fn fn) {
+        try {
+            th_.emplace_back(fn);
+        } catch (const std::system_error &) {
+            fn();
+        }
+    }
+    void join() {
+        for (auto &t : th_)
+            if (t.joinable()) t.join();
+        th_.clear();
+    }
+    ~ThreadGroup() { join(); }
+};
 
 // RAII device buffer.  Throws HipError on failure (mapped to a status at the ABI edge).
 struct DevBuf {
@@ -134,6 +161,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
     void *wsums_host = nullptr;   // pinned
     size_t host_bytes = 0;
     hipEvent_t acc_done = nullptr, red_done = nullptr;
+    hipEvent_t acc_start = nullptr, red_start = nullptr;   // with acc_done / red_done: device time of this MSM's two halves (zkg16_last_timings)
     int nwin = 0, c = 0;
     bool active = false;
     bool pending_reduce = false;    // accumulation queued, reduction not yet (msm_*_enqueue_reduce)
@@ -149,6 +177,7 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
 struct MsmWorkspace {       // grown on demand, reused across proofs
     DevBuf keys, entries, offsets, seg_params, scalars, stage, sort_temp, codes;
     size_t last_tb = 0;         // offsets[last_tb] = length of the term list built last (0: none) — zkg16_last_term_counts
+    uint32_t last_lanes_g1 = 0; // lanes of the G1 accumulation grid the last plan on this workspace asked for (zkg16_last_acc_waves)
 };
 
 }  // namespace zk
@@ -170,7 +199,7 @@ struct zkg16_ctx {
     void *stage_host[2] = {nullptr, nullptr};         // pinned staging ring of upload_h2d (api.hip)
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     zk::DevBuf poly[4];                               // a, b, c, tmp vectors of the witness map
-    float timings[16] = {0};
+    float timings[24] = {0};
     bool kernel_timing = false;
     bool kernel_timing_accumulate_only = false;       // zkg16_kernel_timing(ctx, 2): only the bucket-accumulation launches
     std::map<std::string, zk::KernelStat> kstats;

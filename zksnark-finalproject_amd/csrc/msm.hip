@@ -716,6 +716,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
     // latency — 128x128: 163.0 -> 160.8 ms; no change at 32x32, where a lane would get ~25 terms)
     plan.lanes_g1 = (uint32_t)ctx->num_cus * 4u * (uint32_t)(ctx->opt_g1_waves > 0 ? ctx->opt_g1_waves : tot >= ((size_t)1 << 25) ? 4 : 2) * 64u;
     plan.lanes_g2 = (uint32_t)ctx->num_cus * 4u * 1u * 64u;
+    ws.last_lanes_g1 = plan.lanes_g1;
     ws.seg_params.ensure(2 * sizeof(uint32_t));
     hipLaunchKernelGGL(msm_seg_params_kernel, dim3(1), dim3(64), 0, ctx->stream, ws.offsets.as<uint32_t>() + tb, (uint32_t)tb, plan.lanes_g1,
                        plan.lanes_g2, (uint32_t)(ctx->opt_min_seg > 0 ? ctx->opt_min_seg : 0), ws.seg_params.as<uint32_t>());
@@ -828,6 +829,7 @@ void msm_plan_filter(zkg16_ctx *ctx, const MsmWorkspace &ws_src, const MsmPlan &
     if (plan_src.n == 0) return;
     const size_t tb = plan_src.nb * plan_src.nwin, tot = plan_src.total_entries;
     ws_dst.last_tb = tb;
+    ws_dst.last_lanes_g1 = plan_dst.lanes_g1;
     ws_dst.entries.ensure(tot * sizeof(uint64_t));
     ws_dst.offsets.ensure((tb + 1) * sizeof(uint32_t));
     ws_dst.seg_params.ensure(2 * sizeof(uint32_t));
@@ -911,10 +913,13 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     const size_t tb = plan.nb * plan.nwin;
     const size_t psz = sizeof(XYZZ<F>);
     if (!slot.acc_done) {
-        ZK_HIP(hipEventCreateWithFlags(&slot.acc_done, hipEventDisableTiming));
-        ZK_HIP(hipEventCreateWithFlags(&slot.red_done, hipEventDisableTiming));
+        ZK_HIP(hipEventCreate(&slot.acc_done));
+        ZK_HIP(hipEventCreate(&slot.red_done));
+        ZK_HIP(hipEventCreate(&slot.acc_start));
+        ZK_HIP(hipEventCreate(&slot.red_start));
         if (!slot.stream) ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     }
+    ZK_HIP(hipEventRecord(slot.acc_start, ctx->stream));
     slot.buckets.ensure(tb * psz);
     const size_t nseg = FieldTraits<F>::g2 ? plan.lanes_g2 : plan.lanes_g1;      // lanes of one resident round
     slot.seg_head.ensure(nseg * psz);
@@ -970,6 +975,7 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     struct { XYZZ<F> *buckets; } a{reinterpret_cast<XYZZ<F> *>(slot.red_buckets)};
     hipStream_t aux = slot.stream;
     ZK_HIP(hipStreamWaitEvent(aux, slot.acc_done, 0));
+    ZK_HIP(hipEventRecord(slot.red_start, aux));
     if (slot.fixups_pending) {      // the next accumulation on the main stream does not depend on them
         msm_launch_fixups<F>(ctx, slot, aux);
         slot.fixups_pending = false;

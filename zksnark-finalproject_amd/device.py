@@ -84,6 +84,12 @@ class Device:
         self._check(self.lib.zkg16_last_term_counts(self.ctx, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def last_acc_waves(self):
+        """-> G1 accumulation waves per SIMD of the last proof's (z, B, h) term lists (zkg16_last_acc_waves); 0 = list not built."""
+        out = (C.c_int * 3)()
+        self._check(self.lib.zkg16_last_acc_waves(self.ctx, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def pk_table_bits(self, pk_h):
         """-> (window bits of the z-side tables, of the h-side table); 0 = none (zkg16_pk_table_bits)."""
         bz, bh = C.c_int(0), C.c_int(0)
@@ -242,10 +248,24 @@ class Device:
 
     # ---- instrumentation
     def last_timings(self):
-        buf = (C.c_float * 10)()
-        n = self.lib.zkg16_last_timings(self.ctx, buf, 10)
+        buf = (C.c_float * 20)()
+        n = self.lib.zkg16_last_timings(self.ctx, buf, 20)
         names = ["spmv", "witness_map", "msm_sort", "msm_h", "msm_l", "msm_a", "msm_b1", "msm_b2", "host_tail", "total_wall"]
-        return {names[i]: float(buf[i]) for i in range(n)}
+        out = {names[i]: float(buf[i]) for i in range(min(n, 10))}
+        if n >= 20:
+            # device times under the span names of upstream's prover (ark-groth16 prover.rs): accumulate + fix-ups / bucket reduction
+            acc = dict(zip("HLA", [float(buf[10]), float(buf[11]), float(buf[12])]), B1=float(buf[13]), B2=float(buf[14]))
+            red = dict(zip("HLA", [float(buf[15]), float(buf[16]), float(buf[17])]), B1=float(buf[18]), B2=float(buf[19]))
+            out["device_spans"] = {
+                "R1CS to QAP witness map": out["witness_map"],
+                "scalar digits + bucket scatter": out["msm_sort"],
+                "Compute C": {"h_accumulate": acc["H"], "h_reduce": red["H"], "l_accumulate": acc["L"], "l_reduce": red["L"]},
+                "Compute A": {"accumulate": acc["A"], "reduce": red["A"]},
+                "Compute B in G1": {"accumulate": acc["B1"], "reduce": red["B1"]},
+                "Compute B in G2": {"accumulate": acc["B2"], "reduce": red["B2"]},
+                "Finish C": out["host_tail"],
+            }
+        return out
 
     def kernel_timing(self, enable=True):
         """0/False off, 1/True all kernel families, 2 only the bucket accumulations"""
