@@ -157,6 +157,7 @@ struct WitnessDev { size_t n = 0; DevBuf z; };
 
 struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
     DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list, long_sums, red_a, red_b, red_c;
+    DevBuf bucket_sum;              // an MSM fed in several rounds (streamed assignment): round 0 accumulates here, later rounds into `buckets` and are merged in
     hipStream_t stream = nullptr;   // this MSM's reduction runs here
     void *wsums_host = nullptr;   // pinned
     size_t host_bytes = 0;
@@ -270,7 +271,9 @@ struct MsmPlan {
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const Fr *scalars_canonical, size_t n, MsmPlan &plan, int window_bits = 0);
 // The scalar vector where it lives: n_main elements at `main` then n_extra at `extra`; `mont` = arkworks' Montgomery form
 // (converted inside the digit kernel); mask[i] != 0 zeroes scalar i (B-query density filter).  All device pointers.
-struct ScalarSrc { const Fr *main; size_t n_main; const Fr *extra; size_t n_extra; bool mont; const uint8_t *mask; };
+// part / want_part (streamed assignments, witness.hip): when part != nullptr only the scalars i with part[i] == want_part take
+// part in this plan (the others count as zero: they may not even be computed yet).
+struct ScalarSrc { const Fr *main; size_t n_main; const Fr *extra; size_t n_extra; bool mont; const uint8_t *mask; const uint8_t *part = nullptr; int want_part = 0; };
 void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmPlan &plan, int window_bits = 0, bool tabled = false);
 // window tables of a resident key: bases[n] -> new buffer [254 / c + 1][n], level w = 2^(c w) * base (msm.hip)
 DevBuf msm_tables_build_g1(zkg16_ctx *ctx, const DevBuf &bases, size_t n, int c);
@@ -291,8 +294,10 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
 void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, size_t n);
 // Bases side: window sums -> host; returns the MSM value (XYZZ) after the host Horner.
 // the two halves of an enqueue, for callers that interleave other launches between them (prove_device)
-void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);
-void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot);
+// round: -1 = the whole MSM in one accumulation (default); k >= 0 = round k of an MSM whose terms arrive in several rounds
+// (same plan geometry every round): the rounds' bucket arrays are summed and ONE reduction follows (msm_*_enqueue_reduce)
+void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot, int round = -1);
+void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot, int round = -1);
 void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot);
 void msm_g2_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot);
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot);

@@ -60,6 +60,8 @@ struct DigitSrc {
     size_t n_main, n;
     const uint8_t *mask;
     int mont;
+    const uint8_t *part;       // streamed assignments: only scalars with part[i] == want take part (the others may not exist yet)
+    int want;
 };
 __global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, int nwin, size_t nb, uint64_t *keys, uint32_t *codes, uint32_t invalid_bucket) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,6 +72,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(DigitSrc src, int c, in
         const uint4 *q = reinterpret_cast<const uint4 *>(i < src.n_main ? src.scalars + 8 * i : src.extra + 8 * (i - src.n_main));
         uint4 lo = q[0], hi = q[1];
         if (src.mask && src.mask[i]) lo = hi = make_uint4(0, 0, 0, 0);
+        if (src.part && (int)src.part[i] != src.want) lo = hi = make_uint4(0, 0, 0, 0);
         Fr v;
         v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w; v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
         if (src.mont) v = fp_from_mont(v);
@@ -681,7 +684,7 @@ void msm_plan_build(zkg16_ctx *ctx, MsmWorkspace &ws, const ScalarSrc &src, MsmP
     ws.offsets.ensure((tb + 1) * sizeof(uint32_t));
     const bool own_sort = ctx->opt_sort_mode == 0 || tabled;
     const DigitSrc d{reinterpret_cast<const uint32_t *>(src.main), reinterpret_cast<const uint32_t *>(src.extra), src.n_main, n, src.mask,
-                     src.mont ? 1 : 0};
+                     src.mont ? 1 : 0, src.part, src.want_part};
     const uint32_t *win_total = nullptr;
     if (own_sort) {
         ws.codes.ensure(tot * sizeof(uint32_t));
@@ -903,10 +906,25 @@ static void msm_launch_fixups(zkg16_ctx *ctx, MsmSlot &slot, hipStream_t fs) {
     }
 }
 
+// sum[i] += add[i] for the bucket arrays of two rounds of one MSM (a full XYZZ addition per bucket that got terms in the later
+// round: <= 2^20 buckets per MSM, i.e. microseconds beside the accumulation it follows)
 template <class F>
-static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot) {
-    slot.active = false;
-    slot.pending_reduce = false;
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_bucket_merge_kernel(XYZZ<F> *sum, const XYZZ<F> *add, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const XYZZ<F> b = ldv(add + i);
+    if (b.is_inf()) return;
+    XYZZ<F> a = ldv(sum + i);
+    xyzz_add(a, b);
+    stv(sum + i, a);
+}
+
+template <class F>
+static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const Affine<F> *bases, MsmSlot &slot, int round = -1) {
+    if (round <= 0) {
+        slot.active = false;
+        slot.pending_reduce = false;
+    }
     slot.nwin = plan.nwin;
     slot.c = plan.c;
     if (plan.n == 0) return;
@@ -919,19 +937,26 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
         ZK_HIP(hipEventCreate(&slot.red_start));
         if (!slot.stream) ZK_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     }
-    ZK_HIP(hipEventRecord(slot.acc_start, ctx->stream));
-    slot.buckets.ensure(tb * psz);
+    if (round <= 0) ZK_HIP(hipEventRecord(slot.acc_start, ctx->stream));
+    XYZZ<F> *target;
+    if (round == 0) {
+        slot.bucket_sum.ensure(tb * psz);
+        target = slot.bucket_sum.as<XYZZ<F>>();
+    } else {
+        slot.buckets.ensure(tb * psz);
+        target = slot.buckets.as<XYZZ<F>>();
+    }
     const size_t nseg = FieldTraits<F>::g2 ? plan.lanes_g2 : plan.lanes_g1;      // lanes of one resident round
     slot.seg_head.ensure(nseg * psz);
     slot.seg_tail.ensure(nseg * psz);
     slot.seg_meta.ensure(nseg * 2 * sizeof(int32_t));
     const FixQueue fq = fix_queue<F>(slot, (nseg + 63) / 64 * 64);
-    zero_fill(ctx->stream, slot.buckets.p, tb * psz, fq.counts);      // + the two fix-up queue counters
+    zero_fill(ctx->stream, target, tb * psz, fq.counts);      // + the two fix-up queue counters
     AccArgs<F> a;
     a.bases = bases;
     a.entries = ws.entries.as<uint2>();
     a.offsets = ws.offsets.as<uint32_t>();
-    a.buckets = slot.buckets.as<XYZZ<F>>();
+    a.buckets = target;
     a.seg_head = slot.seg_head.as<XYZZ<F>>();
     a.seg_tail = slot.seg_tail.as<XYZZ<F>>();
     a.seg_meta = slot.seg_meta.as<int32_t>();
@@ -949,11 +974,15 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
     static_assert(sizeof(AccArgs<F>) <= sizeof(slot.acc_args), "MsmSlot::acc_args too small");
     memcpy(slot.acc_args, &a, sizeof a);
     slot.acc_grid = grid;
-    slot.fixups_pending = ctx->opt_fixup_aux != 0;
+    slot.fixups_pending = ctx->opt_fixup_aux != 0 && round < 0;      // rounds are merged right away: their fix-ups come first
     if (!slot.fixups_pending) msm_launch_fixups<F>(ctx, slot, ctx->stream);
+    if (round > 0) {
+        ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_bucket_merge_g2" : "msm_bucket_merge_g1", (double)tb, ctx->stream);
+        hipLaunchKernelGGL(msm_bucket_merge_kernel<F>, dim3((unsigned)((tb + 63) / 64)), dim3(64), 0, ctx->stream, slot.bucket_sum.as<XYZZ<F>>(), target, tb);
+    }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(slot.acc_done, ctx->stream));
-    slot.red_buckets = a.buckets;
+    slot.red_buckets = round >= 0 ? (void *)slot.bucket_sum.as<XYZZ<F>>() : (void *)a.buckets;
     slot.red_nb = plan.nb;
     slot.pending_reduce = true;
 }
@@ -1080,8 +1109,8 @@ static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
     return total;
 }
 
-void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot) { msm_enqueue_acc<FqU>(ctx, ws, plan, bases, slot); }
-void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot) { msm_enqueue_acc<Fq2U>(ctx, ws, plan, bases, slot); }
+void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot, int round) { msm_enqueue_acc<FqU>(ctx, ws, plan, bases, slot, round); }
+void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot, int round) { msm_enqueue_acc<Fq2U>(ctx, ws, plan, bases, slot, round); }
 void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) { msm_enqueue_reduce<FqU>(ctx, slot); }
 void msm_g2_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) { msm_enqueue_reduce<Fq2U>(ctx, slot); }
 void msm_g1_enqueue(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot) { msm_enqueue<FqU>(ctx, ws, plan, bases, slot); }
