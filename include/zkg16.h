@@ -237,6 +237,14 @@ ZKG16_API int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_p
  * (upload + kernels), whole call. */
 ZKG16_API int zkg16_witness_matrix(zkg16_ctx *ctx, size_t n, const uint64_t *a, const uint64_t *b, uint64_t *witness_handle,
                          uint64_t public_inputs[12], float *timings_ms);
+/* One request of the matrix handler on a key and matrices that are resident: assignment + proof, overlapped — the host sponges feed
+ * the device in parts (option "matrix_parts", default five growing slices) and the z-side MSMs run on the parts that exist while the sponges
+ * still compute the rest; same proof bytes as zkg16_witness_matrix + zkg16_prove_resident.  r1cs_handle / pk_handle must be the
+ * MatrixCircuit of size n (else ZKG16_ERR_BAD_ARG).  public_inputs (nullable): hash_a | hash_b | hash_c.  timings_ms (nullable, 3):
+ * host sponges (wall, overlapped with the device), parts used, whole call. */
+ZKG16_API int zkg16_prove_matrix(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, size_t n, const uint64_t *a, const uint64_t *b,
+                       const uint64_t r[4], const uint64_t s[4], uint64_t proof_out[48], uint8_t inf_out[3], uint64_t public_inputs[12],
+                       float *timings_ms);
 /* Its host-only half (no ctx, no GPU): states (nullable) = 3 hashes x ceil(n^2/2) permutations x 3 Fr, the sponge state in
  * front of each permutation (after its two elements were absorbed); hashes = hash_a | hash_b | hash_c. */
 ZKG16_API int zkg16_matrix_sponge_states(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *states, uint64_t hashes[12]);
@@ -302,6 +310,7 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
  *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
+ *   "matrix_parts"   zkg16_prove_matrix: slices of the host sponges the proof is fed in (0 = five growing slices, k = k equal ones; 1 = assignment first, then the proof)
  * Unknown names return ZKG16_ERR_UNSUPPORTED. */
 ZKG16_API int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value);
 

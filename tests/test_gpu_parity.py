@@ -828,3 +828,43 @@ def test_full_size_request_verifies_with_tables(dev):
     assert verify(vk, bad, *tabled) is False
     for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
         f(h)
+
+
+@pytest.mark.parametrize("n,tables,parts", [(8, False, 0), (33, False, 0), (46, True, 0), (46, False, 8), (46, True, 1), (128, True, 0)])
+def test_prove_matrix_streamed_equals_two_step(dev, n, tables, parts):
+    """zkg16_prove_matrix: the assignment arrives on the device in parts while the z-side MSMs already run on the parts that exist
+    (rounds summed bucket-wise, one reduction) -> the same proof bytes as zkg16_witness_matrix + zkg16_prove_resident on the same key,
+    r, s; pairing-verified; with and without window tables, several slice counts (parts = 1: no overlap), random full-range inputs."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    from zksnark_finalproject_amd.device import scalar_mul, verify
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    rng_np = np.random.default_rng(4000 + n)
+    a = rng_np.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    b = rng_np.integers(0, 1 << 63, size=(n, n), dtype=np.uint64)
+    circ = matrix_circuit(a, b)
+    rng = random.Random(n)
+    trap = np.stack([fr_mont(P.rand_fr(rng)) for _ in range(5)])
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    g1, g2 = scalar_mul("g1", g1_generator(), k)[0], scalar_mul("g2", g2_generator(), k)[0]
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
+    if tables:
+        dev.pk_precompute(ph, 17 if n < 100 else 0, 17 if n < 100 else 0)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    wh, pub, _ = dev.witness_matrix(a, b)
+    want = dev.prove_resident(ph, rh, wh, r, s)
+    dev.set_option("matrix_parts", parts)
+    try:
+        for _ in range(2):                       # twice: the second call reuses every workspace of the first
+            proof, inf, pub2, ms = dev.prove_matrix(ph, rh, a, b, r, s)
+            assert np.array_equal(pub2, circ.public_inputs) and np.array_equal(pub, pub2)
+            assert np.array_equal(proof, want[0]) and np.array_equal(inf, want[1]), "streamed proof differs (parts used: %d)" % ms["parts"]
+    finally:
+        dev.set_option("matrix_parts", 0)
+    assert verify(vk, circ.public_inputs, proof, inf) is True
+    after = dev.prove_resident(ph, rh, wh, r, s)                 # and the ordinary path still works on the same slots afterwards
+    assert np.array_equal(after[0], want[0])
+    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(h)
+    with pytest.raises(Exception):
+        dev.prove_matrix(ph, rh, a, b, r, s)                     # freed handles

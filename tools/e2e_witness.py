@@ -52,5 +52,16 @@ for _ in range(reps):
     dev.witness_free(w)
     print("device assignment %.1f (sponges %.1f, device %.2f) + prove %.1f = %.1f ms" %
           ((t1 - t0) * 1e3, ms["host_sponges_ms"], ms["device_ms"], (t2 - t1) * 1e3, (t2 - t0) * 1e3))
+for parts in (0, 2, 3, 6, 8, 1):
+    dev.set_option("matrix_parts", parts)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        p_st, i_st, pub, ms = dev.prove_matrix(ph, rh, ones, ones, r, s)
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None or dt < best else best
+    print("prove_matrix matrix_parts=%d (parts used %d): best %.1f ms (sponges %.1f ms overlapped), same proof: %s" %
+          (parts, ms["parts"], best, ms["host_sponges_ms"], bool(np.array_equal(p_st, p_new[0]))))
+dev.set_option("matrix_parts", 0)
 print("same proof:", bool(np.array_equal(p_old[0], p_new[0])), "verified:", verify(vk, circ.public_inputs, *p_new))
 dev.close()

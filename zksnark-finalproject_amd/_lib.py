@@ -69,6 +69,7 @@ SIGNATURES = {
     "zkg16_circuit_export": (C.c_int, [vp, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3), u64p]),
     "zkg16_poseidon_hash": (C.c_int, [u64p, sz, u64p]),
     "zkg16_witness_matrix": (C.c_int, [ctxp, sz, u64p, u64p, C.POINTER(H), vp, vp]),
+    "zkg16_prove_matrix": (C.c_int, [ctxp, H, H, sz, u64p, u64p, u64p, u64p, u64p, u8p, vp, vp]),
     "zkg16_matrix_sponge_states": (C.c_int, [sz, u64p, u64p, vp, u64p]),
     "zkg16_ntt": (C.c_int, [ctxp, u64p, sz, C.c_int, C.c_int]),
     "zkg16_msm_g1": (C.c_int, [ctxp, vp, vp, vp, sz, u64p, u8p]),

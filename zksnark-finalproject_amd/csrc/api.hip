@@ -223,7 +223,7 @@ double now_ms() {
 
 // events of one proof, destroyed on every exit path
 struct EventSet {
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     EventSet() { for (auto &e : ev) ZK_HIP(hipEventCreate(&e)); }
     ~EventSet() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
     EventSet(const EventSet &) = delete;
@@ -234,8 +234,12 @@ struct EventSet {
 // [z_lo, z_hi) of the a / b_g1 / b_g2 / l queries and [h_lo, h_hi) of h_query.  A rank whose h range is empty skips the
 // witness map and the H MSM altogether, one whose z range is empty (and which does not carry the r, s, -rs terms) skips the
 // four z-side MSMs — this is what lets the ranks of a multi-GPU proof take different roles (zkg16_shard_plan).
+// zp (zkg16_prove_matrix): the assignment is still being produced — part k of it becomes valid when zp->produce(k) has queued
+// its kernels on the main stream.  The z-side MSMs then run in rounds, one per part, over the terms of that part only (digits
+// of the other scalars count as zero), each round's buckets are summed into the MSM's bucket array and ONE reduction follows;
+// the witness map waits for the last part.
 void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const Fr &r, const Fr &s, Partials &out,
-                  const std::function<void()> *before_witness_map = nullptr) {
+                  const std::function<void()> *before_witness_map = nullptr, const ZParts *zp = nullptr) {
     const size_t m_total = rc.num_variables;
     if (wit.n != m_total || pk.m_total != m_total) throw HipError{hipErrorInvalidValue, "prove: assignment / key length mismatch", __FILE__, __LINE__};
     const size_t N = (size_t)1 << rc.log_n;
@@ -274,29 +278,8 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
     MsmWorkspace &wsb = b_sparse ? ctx->ws_zb : ctx->ws_z;
     const MsmPlan &planb = b_sparse ? plan_zb : plan_z;
-    if (z_side) {
-        if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
-        Fr *extra = reinterpret_cast<Fr *>(ctx->extra_host);
-        extra[0] = pk.blinding ? r : Fr::zero();              // the r/s/-rs terms are added by one shard only
-        extra[1] = pk.blinding ? s : Fr::zero();
-        extra[2] = pk.blinding ? fp_neg(fp_mul(r, s)) : Fr::zero();
-        // the digit kernel reads the three extra scalars straight from this pinned (device-visible) host buffer: no host-to-device
-        // copy is queued; the buffer is rewritten only by the next proof, which starts after this one has been collected
-        ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, extra, 3, true, nullptr};
-        const int tz = pk.tab_c_z;
-        msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z, tz, tz != 0);
-        if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
-            // (measured: 128x128 with window tables 154.5 -> 153.65 ms, 32x32 11.97 -> 11.68; with a plain key 168.55 -> 169.2, so only with tables
-            // unless option b_filter = 1 asks for it)
-            if ((ctx->opt_b_filter == 1 || (ctx->opt_b_filter == 0 && tz != 0)) && ctx->opt_sort_mode == 0) {
-                msm_plan_filter(ctx, ctx->ws_z, plan_z, pk.b_mask.as<uint8_t>(), ctx->ws_zb, plan_zb);
-            } else {
-                zsrc.mask = pk.b_mask.as<uint8_t>();
-                msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb, tz, tz != 0);
-            }
-        }
-    }
-    ZK_HIP(hipEventRecord(ev[1], ctx->stream));
+    const int parts = zp ? zp->parts : 1;
+    const bool rounds = parts > 1 && z_side && zp->part_of != nullptr;
     // ---- the four z-side accumulations go onto the main stream BEFORE the witness map's ~40 launches (G2 first: its long
     // reduction then hides behind the G1 accumulations); their reductions — whose first packet is a wait — only after those
     // launches (msm_enqueue_reduce).  Kernel trace at n = 32: queued after the witness map, the G2 accumulation started
@@ -305,20 +288,51 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     // accumulation, with the witness map held back until the first list exists — the accumulation then starts 9 instead of
     // 15 ms into the proof, and the proof takes the same 171-172 ms: kernels that share the device slow each other by about
     // what the overlap saves, the proof is the SUM of its kernels' work.  A high-priority witness-map stream: +1 ms.)
-    auto enqueue_z_accs = [&]() {
+    auto enqueue_z_accs = [&](int round) {
         if (!z_side) return;
-        msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0]);
-        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2]);
-        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3]);
-        msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4]);
+        msm_g2_enqueue_acc(ctx, wsb, planb, pk.b2.as<G2AffineU>(), ctx->slots[0], round);
+        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.l.as<G1AffineU>(), ctx->slots[2], round);
+        msm_g1_enqueue_acc(ctx, ctx->ws_z, plan_z, pk.a.as<G1AffineU>(), ctx->slots[3], round);
+        msm_g1_enqueue_acc(ctx, wsb, planb, pk.b1.as<G1AffineU>(), ctx->slots[4], round);
     };
+    if (zp && !rounds)
+        for (int k = 0; k < parts; k++) zp->produce(k);       // no rounds (one part, or no z side here): the whole assignment first
+    if (z_side) {
+        if (!ctx->extra_host) ZK_HIP(hipHostMalloc(&ctx->extra_host, 3 * sizeof(Fr), hipHostMallocDefault));
+        Fr *extra = reinterpret_cast<Fr *>(ctx->extra_host);
+        extra[0] = pk.blinding ? r : Fr::zero();              // the r/s/-rs terms are added by one shard only
+        extra[1] = pk.blinding ? s : Fr::zero();
+        extra[2] = pk.blinding ? fp_neg(fp_mul(r, s)) : Fr::zero();
+        // the digit kernel reads the three extra scalars straight from this pinned (device-visible) host buffer: no host-to-device
+        // copy is queued; the buffer is rewritten only by the next proof, which starts after this one has been collected
+        for (int k = 0; k < (rounds ? parts : 1); k++) {
+            if (rounds) zp->produce(k);
+            ScalarSrc zsrc{wit.z.as<Fr>() + pk.z_lo, nz, extra, 3, true, nullptr};
+            if (rounds) { zsrc.part = zp->part_of; zsrc.want_part = k; }
+            const int tz = pk.tab_c_z;
+            msm_plan_build(ctx, ctx->ws_z, zsrc, plan_z, tz, tz != 0);
+            if (b_sparse) {      // B1 and B2 share a plan without the terms whose bases are infinity (see b_density_mask_kernel)
+                // (measured: 128x128 with window tables 154.5 -> 153.65 ms, 32x32 11.97 -> 11.68; with a plain key 168.55 -> 169.2, so only with tables
+                // unless option b_filter = 1 asks for it)
+                if ((ctx->opt_b_filter == 1 || (ctx->opt_b_filter == 0 && tz != 0)) && ctx->opt_sort_mode == 0) {
+                    msm_plan_filter(ctx, ctx->ws_z, plan_z, pk.b_mask.as<uint8_t>(), ctx->ws_zb, plan_zb);
+                } else {
+                    zsrc.mask = pk.b_mask.as<uint8_t>();
+                    msm_plan_build(ctx, ctx->ws_zb, zsrc, plan_zb, tz, tz != 0);
+                }
+            }
+            if (rounds) enqueue_z_accs(k);
+        }
+    }
+    ZK_HIP(hipEventRecord(ev[1], ctx->stream));
+    if (zp) ZK_HIP(hipEventRecord(ev[5], ctx->stream));       // z is complete once the main stream gets here
     // the z-side accumulations either start at once (their kernels and the witness map's then share the device) or wait for the
     // witness map, which then has the device to itself and lets the h-side sort run underneath the accumulations.  Measured: with
     // window tables 128x128 154.5 vs 153.65 ms (32x32 11.7 vs 12.2, 46x46 19.7 vs 20.3), with a plain key 128x128 168.6 vs 171.2 —
     // so by default only from 2^23 on and only for keys with tables; never when the matrices are still being uploaded on the
     // witness map's stream (the accumulations are what hides that).
-    const int wm_first = !nh ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : (rc.log_n >= 23 && pk.tab_c_h != 0 && !before_witness_map) ? 1 : 0;
-    if (!wm_first) enqueue_z_accs();
+    const int wm_first = (!nh || rounds) ? 0 : ctx->opt_wm_first >= 0 ? ctx->opt_wm_first : (rc.log_n >= 23 && pk.tab_c_h != 0 && !before_witness_map) ? 1 : 0;
+    if (!wm_first && !rounds) enqueue_z_accs(-1);
 
     // ---- R1CS -> QAP witness map (a3-a5 of SURVEY.md 8a) and the h-side sort, on a third stream concurrently with the
     // z-side work (measured in one process, n = 32: 18.15 vs 18.58 ms in order; n = 12: 10.05 vs 11.16 ms)
@@ -328,6 +342,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
         // zkg16_prove (host pointers): the matrices are uploaded here, on the witness map's stream, while the z-side
         // accumulations queued above already keep the device busy
         if (before_witness_map) (*before_witness_map)();
+        if (zp) ZK_HIP(hipStreamWaitEvent(ctx->stream, ev[5], 0));
         ZK_HIP(hipEventRecord(ev[2], ctx->stream));
         Fr *h = nullptr;
         if (nh) witness_map_run(ctx, rc, wit.z.as<Fr>(), &h);
@@ -344,7 +359,7 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     if (wm_concurrent) std::swap(ctx->stream, ctx->wm_stream);
     if (wm_first) {
         ZK_HIP(hipStreamWaitEvent(ctx->stream, wm_first == 2 ? ev[4] : ev[3], 0));
-        enqueue_z_accs();
+        enqueue_z_accs(-1);
     }
 
     if (z_side) {
@@ -767,6 +782,11 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_b_filter = (int)value;
         return ZKG16_OK;
     }
+    if (!strcmp(name, "matrix_parts")) {       // zkg16_prove_matrix: slices of the host sponges the proof is fed in (0 = five growing slices; k = k equal ones; 1 = no overlap: assignment first)
+        if (value < 0 || value > 8) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_matrix_parts = (int)value;
+        return ZKG16_OK;
+    }
     if (!strcmp(name, "reduce_chunk")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return ZKG16_ERR_BAD_ARG;
         ctx->opt_reduce_chunk = (int)value;
@@ -1180,6 +1200,60 @@ int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handl
     prove_tail(*pk, rr, ss, p, proof_out, inf_out);
     ctx->timings[8] = (float)(now_ms() - t0);
     ctx->timings[9] += ctx->timings[8];
+    ZK_API_END(ctx)
+}
+
+// One MatrixCircuit request on matrices that are already resident: what the reference times as `proving_time`
+// (matrix_proof.rs:138-145: Groth16::prove re-synthesises the circuit, then proves) with the per-request part of the synthesis —
+// the assignment — produced WHILE the proof runs.  The three native sponges run on three host threads (sequential by
+// construction); as soon as a quarter of their permutations is done the device expands those into their S-box values and the four
+// z-side MSMs start on the terms that exist (prove_device's rounds); the witness map and the H MSM follow the last part.
+int zkg16_prove_matrix(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, size_t n, const uint64_t *a, const uint64_t *b,
+                       const uint64_t r[4], const uint64_t s[4], uint64_t proof_out[48], uint8_t inf_out[3], uint64_t public_inputs[12],
+                       float *timings_ms) {
+    if (!r || !s || !proof_out || !inf_out || !a || !b || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
+    if (!ctx) return ZKG16_ERR_BAD_ARG;
+    const double t_call = now_ms();
+    std::unique_ptr<MatrixWitnessStream, void (*)(MatrixWitnessStream *)> ms(nullptr, matrix_stream_free);
+    try {
+        // the chains start before the ctx is locked: they need neither it nor the device
+        ms.reset(matrix_stream_start(n, a, b, ctx->opt_matrix_parts, ctx->opt_matrix_parts != 1));
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    }
+    ZK_API_BEGIN(ctx)
+    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    if (!pk || !rc) return ZKG16_ERR_BAD_HANDLE;
+    if (!pk->full) return ZKG16_ERR_BAD_ARG;
+    const size_t total = matrix_stream_total(ms.get());
+    if (total != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != 4 || rc->num_instance != 4 ||
+        pk->n_h_total != ((size_t)1 << rc->log_n) - 1)
+        return ZKG16_ERR_BAD_ARG;                   // not the MatrixCircuit of this size
+    WitnessDev wit;
+    wit.n = total;
+    wit.z.alloc(total * sizeof(Fr));
+    // a throw below must not leave the stream object's copies and kernels in flight behind its destruction
+    struct Drain { zkg16_ctx *c; ~Drain() { (void)hipStreamSynchronize(c->stream); } } drain{ctx};
+    matrix_stream_attach(ms.get(), ctx, wit.z.as<Fr>(), 3);
+    ZParts zp;
+    zp.parts = matrix_stream_parts(ms.get());
+    zp.part_of = matrix_stream_part_of(ms.get());
+    MatrixWitnessStream *msp = ms.get();
+    zp.produce = [ctx, msp](int k) { matrix_stream_produce(msp, ctx, k); };
+    Partials p;
+    const Fr rr = fr_from_abi(r), ss = fr_from_abi(s);
+    prove_device(ctx, *pk, *rc, wit, rr, ss, p, nullptr, &zp);      // without part_of (matrix_parts = 1): the assignment first, then the proof
+    const double t0 = now_ms();
+    prove_tail(*pk, rr, ss, p, proof_out, inf_out);
+    ctx->timings[8] = (float)(now_ms() - t0);
+    ctx->timings[9] += ctx->timings[8];
+    if (public_inputs) matrix_stream_hashes(ms.get(), public_inputs);
+    if (timings_ms) {
+        timings_ms[0] = (float)matrix_stream_chain_ms(ms.get());
+        timings_ms[1] = (float)zp.parts;
+        timings_ms[2] = (float)(now_ms() - t_call);
+    }
     ZK_API_END(ctx)
 }
 

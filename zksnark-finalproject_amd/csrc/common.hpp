@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -222,6 +223,7 @@ struct zkg16_ctx {
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
     int opt_acc_pipeline = 0;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product (default: neither)
+    int opt_matrix_parts = 0;                         // zkg16_prove_matrix: gadget slices the assignment arrives in (0 = five growing slices, k = k equal ones, 1 = no overlap)
     int opt_fuse_pointwise = 1;                       // (ab - c)/Z on the load of the seventh transform (0: its own pass)
     int num_cus = 256;
     bool lds_attr_fixup[2] = {false, false}, lds_attr_ntt = false;      // hipFuncSetAttribute(max dynamic LDS) done on this device
@@ -309,6 +311,28 @@ G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const 
 // saturated (arkworks) affine points -> the unsaturated device form, on the ctx stream
 void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n);
 void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n);
+
+// witness.hip: the MatrixCircuit's assignment arriving on the device in parts (zkg16_witness_matrix: all at once;
+// zkg16_prove_matrix: while the proof is already running).  slices_wanted gadget slices -> parts = slices + 1.
+struct MatrixWitnessStream;
+MatrixWitnessStream *matrix_stream_start(size_t n, const uint64_t *a, const uint64_t *b, int slices_wanted, bool overlap);   // host chains start here
+int matrix_stream_parts(const MatrixWitnessStream *ms);
+size_t matrix_stream_total(const MatrixWitnessStream *ms);
+const uint8_t *matrix_stream_part_of(const MatrixWitnessStream *ms);       // device, total + n_extra bytes (null with one slice)
+void matrix_stream_attach(MatrixWitnessStream *ms, zkg16_ctx *ctx, Fr *z, size_t n_extra);
+void matrix_stream_produce(MatrixWitnessStream *ms, zkg16_ctx *ctx, int k);  // blocks for the chains, then queues part k on ctx->stream
+double matrix_stream_chain_ms(const MatrixWitnessStream *ms);
+void matrix_stream_hashes(const MatrixWitnessStream *ms, uint64_t out[12]);
+void matrix_stream_free(MatrixWitnessStream *ms);
+
+// An assignment that becomes valid in parts while its proof is already running (prove_device): produce(k) blocks until part k
+// can be made, then queues on ctx->stream whatever writes it; part_of[i] = the part variable i (and the trailing r, s, -rs slots)
+// belongs to.
+struct ZParts {
+    int parts = 1;
+    const uint8_t *part_of = nullptr;
+    std::function<void(int)> produce;
+};
 
 size_t b_density_mask_run(zkg16_ctx *ctx, const G1AffineU *b1, const G2AffineU *b2, size_t n, uint8_t *mask);
 // device outputs; either may be null: saturated (arkworks layout, host-bound) and/or unsaturated (device-resident key)

@@ -76,47 +76,67 @@ struct MatrixChains {
     std::vector<Fr64> elems[3];         // a, b, c as Montgomery Fr
     std::vector<Fr64> states[3];        // perms x 3 each
     Fr64 hash[3];
-    std::atomic<size_t> done[3];
+    std::atomic<size_t> done[3];        // permutations of chain h whose entering state has been written
+    std::thread th[3];
+    bool started[3] = {false, false, false};
+    std::chrono::steady_clock::time_point t0;
     double chain_ms = 0;
-};
+    const uint64_t *a = nullptr, *b = nullptr;
 
-// the three chains, one host thread each (the third multiplies the matrices first); returns when all are done
-void run_chains(MatrixChains &mc, size_t n, const uint64_t *a, const uint64_t *b) {
-    const auto t0 = std::chrono::steady_clock::now();
-    mc.n = n;
-    mc.nn = n * n;
-    mc.perms = (mc.nn + POSEIDON_RATE - 1) / POSEIDON_RATE;
-    for (int h = 0; h < 3; h++) {
-        mc.elems[h].resize(mc.nn);
-        mc.states[h].resize(3 * mc.perms);
-        mc.done[h].store(0);
-    }
-    (void)pparams();
-    auto chain = [&](int h) {
-        if (h == 2) matmul_u64(n, a, b, mc.elems[2].data());
+    void chain(int h) {
+        if (h == 2) matmul_u64(n, a, b, elems[2].data());
         else {
             const uint64_t *src = h == 0 ? a : b;
-            for (size_t i = 0; i < mc.nn; i++) mc.elems[h][i] = fr64_from_u64(src[i]);
+            for (size_t i = 0; i < nn; i++) elems[h][i] = fr64_from_u64(src[i]);
         }
-        mc.hash[h] = sponge_chain(mc.elems[h].data(), mc.nn, mc.states[h].data(), &mc.done[h]);
-    };
-    // a thread that cannot be started (EAGAIN) is not fatal: its chain runs here instead
-    std::thread th[2];
-    bool started[2] = {false, false};
-    for (int h = 0; h < 2; h++) {
-        try {
-            th[h] = std::thread(chain, h);
-            started[h] = true;
-        } catch (const std::system_error &) {
+        hash[h] = sponge_chain(elems[h].data(), nn, states[h].data(), &done[h]);
+    }
+    // the three chains, one host thread each (the third multiplies the matrices first).  inline_last: the third chain runs on the
+    // calling thread (the one-shot entry point: nothing to overlap it with); otherwise all three run beside the caller, which
+    // feeds the device from their progress (zkg16_prove_matrix).  a, b must stay valid until join().
+    void start(size_t n_, const uint64_t *a_, const uint64_t *b_, bool inline_last) {
+        t0 = std::chrono::steady_clock::now();
+        n = n_; nn = n * n; a = a_; b = b_;
+        perms = (nn + POSEIDON_RATE - 1) / POSEIDON_RATE;
+        for (int h = 0; h < 3; h++) {
+            elems[h].resize(nn);
+            states[h].resize(3 * perms);
+            done[h].store(0);
+        }
+        (void)pparams();
+        // a thread that cannot be started (EAGAIN) is not fatal: its chain runs on the caller instead (in join at the latest)
+        for (int h = 0; h < (inline_last ? 2 : 3); h++) {
+            try {
+                th[h] = std::thread([this, h]() { chain(h); });
+                started[h] = true;
+            } catch (const std::system_error &) {
+            }
+        }
+        if (inline_last) { chain(2); ran_inline[2] = true; }
+    }
+    bool ran_inline[3] = {false, false, false};
+    bool joined = false;
+    void join() {
+        if (joined) return;
+        for (int h = 0; h < 3; h++) {
+            if (started[h]) { th[h].join(); started[h] = false; ran_inline[h] = true; }
+            else if (!ran_inline[h]) { chain(h); ran_inline[h] = true; }
+        }
+        chain_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        joined = true;
+    }
+    // blocks until every chain has recorded the entering states of its permutations [0, upto)
+    void wait_for(size_t upto) {
+        for (int h = 0; h < 3; h++) {
+            if (!started[h] && !ran_inline[h]) { chain(h); ran_inline[h] = true; }      // its thread never started
+            while (done[h].load(std::memory_order_acquire) < upto) std::this_thread::sleep_for(std::chrono::microseconds(30));
         }
     }
-    chain(2);
-    for (int h = 0; h < 2; h++) {
-        if (started[h]) th[h].join();
-        else chain(h);
+    ~MatrixChains() {
+        for (int h = 0; h < 3; h++)
+            if (started[h]) th[h].join();
     }
-    mc.chain_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
+};
 
 // ------------------------------------------------------------------------------------------------ device
 struct PoseidonDev { Fr mds[3][3], ark[P_ROUNDS][3]; };
@@ -206,6 +226,35 @@ __global__ void __launch_bounds__(64) wit_sponge_kernel(SpongeArgs g) {
     }
 }
 
+// part_of[i] = the part of a streamed assignment in which variable i becomes valid: 0 = what needs only a and b (the constant,
+// a, b, the zeros, the products; also the three trailing r / s / -rs slots of the z-side scalar vector), 1 + s = the S-box
+// values of the permutations of slice s of every sponge, the last part also the three hashes.
+struct PartArgs {
+    uint8_t *part_of;
+    size_t total, n_all, off_ha, off_hb, off_mc, off_hc, hw;
+    uint32_t bounds[10];
+    int slices;
+};
+__global__ void __launch_bounds__(256) wit_part_of_kernel(PartArgs g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n_all) return;
+    int part = 0;
+    if (i >= 1 && i <= 3) part = g.slices;
+    else if (i < g.total) {
+        size_t o = g.total;
+        if (i >= g.off_ha && i < g.off_ha + g.hw) o = i - g.off_ha;
+        else if (i >= g.off_hb && i < g.off_hb + g.hw) o = i - g.off_hb;
+        else if (i >= g.off_hc) o = i - g.off_hc;
+        if (o != g.total) {
+            const uint32_t p = o < PERM_WITNESSES - FIRST_PERM_SKIPPED ? 0u : (uint32_t)((o + FIRST_PERM_SKIPPED) / PERM_WITNESSES);
+            int sl = 0;
+            while (sl + 1 < g.slices && p >= g.bounds[sl + 1]) sl++;
+            part = 1 + sl;
+        }
+    }
+    g.part_of[i] = (uint8_t)part;
+}
+
 }  // namespace
 
 namespace zk {
@@ -220,6 +269,121 @@ struct MatrixWitnessLayout {
     }
 };
 
+// The assignment of one MatrixCircuit request arriving on the device in parts: part 0 needs only a and b, part 1 + s the
+// entering states of slice s of the three host chains (common.hpp: MatrixWitnessStream is opaque to api.hip).
+struct MatrixWitnessStream {
+    MatrixWitnessLayout L;
+    MatrixChains mc;
+    int slices = 1;
+    bool overlap = false;                   // the proof runs while the parts arrive: part_of is built
+    std::vector<uint32_t> bounds;           // slices + 1 permutation indices
+    DevBuf d_ab, d_states, part_of;
+    Fr *z = nullptr;
+    const uint64_t *a = nullptr, *b = nullptr;
+    Fr inst[3];
+    explicit MatrixWitnessStream(size_t n) : L(n) {}
+};
+
+MatrixWitnessStream *matrix_stream_start(size_t n, const uint64_t *a, const uint64_t *b, int slices_wanted, bool overlap) {
+    auto *ms = new MatrixWitnessStream(n);
+    ms->a = a; ms->b = b;
+    const size_t perms = (ms->L.nn + POSEIDON_RATE - 1) / POSEIDON_RATE;
+    // slices_wanted = 0: growing slices.  The device needs longer for a slice's terms than the host chain for its states
+    // (128x128: 84 ms of z-side accumulation against 61 ms of chain), so once started it never waits again — what counts is
+    // starting early: a first slice of 6 %, each later one about as long as the device is busy with the one before.
+    static const double grow[5] = {0.06, 0.20, 0.45, 0.80, 1.0};
+    int k = slices_wanted == 0 ? 5 : slices_wanted < 1 ? 1 : slices_wanted > 8 ? 8 : slices_wanted;
+    const bool growing = slices_wanted == 0 && perms >= 4096;
+    if (!growing && slices_wanted == 0) k = 4;
+    while (k > 1 && !growing && perms / k < 512) k--;          // a slice shorter than ~4 ms of host chain is all fixed cost on the device side
+    ms->slices = overlap ? k : 1;
+    ms->overlap = overlap;
+    ms->bounds.resize(ms->slices + 1);
+    for (int i = 0; i <= ms->slices; i++)
+        ms->bounds[i] = (growing && overlap) ? (i == 0 ? 0u : (uint32_t)((double)perms * grow[i - 1] + 0.5)) : (uint32_t)(perms * (size_t)i / ms->slices);
+    ms->bounds[ms->slices] = (uint32_t)perms;
+    try {
+        ms->mc.start(n, a, b, !overlap);
+    } catch (...) {
+        delete ms;
+        throw;
+    }
+    return ms;
+}
+int matrix_stream_parts(const MatrixWitnessStream *ms) { return ms->slices + 1; }
+size_t matrix_stream_total(const MatrixWitnessStream *ms) { return ms->L.total; }
+const uint8_t *matrix_stream_part_of(const MatrixWitnessStream *ms) { return ms->overlap ? ms->part_of.as<uint8_t>() : nullptr; }
+double matrix_stream_chain_ms(const MatrixWitnessStream *ms) { return ms->mc.chain_ms; }
+void matrix_stream_hashes(const MatrixWitnessStream *ms, uint64_t out[12]) {
+    for (int h = 0; h < 3; h++) memcpy(out + 4 * h, ms->mc.hash[h].l, 32);
+}
+void matrix_stream_free(MatrixWitnessStream *ms) { delete ms; }
+
+// device buffers of the request; z: total (+ whatever the caller appends) elements.  n_extra: trailing slots of the z-side scalar
+// vector (r, s, -rs) that part_of must cover too.
+void matrix_stream_attach(MatrixWitnessStream *ms, zkg16_ctx *ctx, Fr *z, size_t n_extra) {
+    const MatrixWitnessLayout &L = ms->L;
+    if (!ctx->poseidon_dev.p) {
+        const PoseidonH &ph = pparams();
+        PoseidonDev pd;
+        static_assert(sizeof(PoseidonDev) == sizeof(Fr64) * (9 + 3 * P_ROUNDS), "layout");
+        memcpy(pd.mds, ph.mds, sizeof pd.mds);
+        memcpy(pd.ark, ph.ark, sizeof pd.ark);
+        ctx->poseidon_dev.alloc(sizeof pd);
+        ZK_HIP(hipMemcpy(ctx->poseidon_dev.p, &pd, sizeof pd, hipMemcpyHostToDevice));
+    }
+    ms->z = z;
+    ms->d_ab.alloc(2 * L.nn * sizeof(uint64_t));
+    ms->d_states.alloc(3 * ms->mc.perms * 3 * sizeof(Fr));
+    if (ms->overlap) {
+        const size_t n_all = L.total + n_extra;
+        ms->part_of.alloc(n_all);
+        PartArgs g;
+        g.part_of = ms->part_of.as<uint8_t>();
+        g.total = L.total; g.n_all = n_all; g.off_ha = L.off_ha; g.off_hb = L.off_hb; g.off_mc = L.off_mc; g.off_hc = L.off_hc; g.hw = L.hw;
+        g.slices = ms->slices;
+        for (int i = 0; i <= ms->slices; i++) g.bounds[i] = ms->bounds[i];
+        hipLaunchKernelGGL(wit_part_of_kernel, dim3((unsigned)((n_all + 255) / 256)), dim3(256), 0, ctx->stream, g);
+        ZK_HIP(hipGetLastError());
+    }
+}
+
+// Queues on ctx->stream what makes part k of z valid; blocks on the host first until the chains have got that far.
+void matrix_stream_produce(MatrixWitnessStream *ms, zkg16_ctx *ctx, int k) {
+    const MatrixWitnessLayout &L = ms->L;
+    Fr *z = ms->z;
+    if (k == 0) {
+        ZK_HIP(hipMemcpyAsync(ms->d_ab.p, ms->a, L.nn * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(ms->d_ab.as<uint64_t>() + L.nn, ms->b, L.nn * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        FillArgs g;
+        g.a = ms->d_ab.as<uint64_t>(); g.b = g.a + L.nn; g.z = z; g.n = L.n; g.nn = L.nn;
+        g.off_a = L.off_a; g.off_mc = L.off_mc; g.off_mm = L.off_mm; g.total = 3 * L.nn + L.nn * (L.n + 1);
+        ScopedKernelTimer kt(ctx, "wit_matrix_fill_kernel", (double)g.total);
+        hipLaunchKernelGGL(wit_matrix_fill_kernel, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, ctx->stream, g);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+    const uint32_t p_lo = ms->bounds[k - 1], p_hi = ms->bounds[k];
+    const size_t perms = ms->mc.perms;
+    if (k == ms->slices) ms->mc.join();          // the hashes exist once the chains have ended
+    else ms->mc.wait_for(p_hi);
+    for (int h = 0; h < 3; h++)
+        ZK_HIP(hipMemcpyAsync(ms->d_states.as<Fr>() + (size_t)h * 3 * perms + 3 * (size_t)p_lo, ms->mc.states[h].data() + 3 * (size_t)p_lo,
+                              3 * (size_t)(p_hi - p_lo) * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    if (k == ms->slices) {
+        for (int h = 0; h < 3; h++) memcpy(ms->inst[h].l, ms->mc.hash[h].l, 32);
+        ZK_HIP(hipMemcpyAsync(z + 1, ms->inst, sizeof ms->inst, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SpongeArgs g;
+    for (int h = 0; h < 3; h++) g.states[h] = ms->d_states.as<Fr>() + (size_t)h * 3 * perms;
+    g.out[0] = z + L.off_ha; g.out[1] = z + L.off_hb; g.out[2] = z + L.off_hc;
+    g.params = ctx->poseidon_dev.as<PoseidonDev>();
+    g.p_lo = p_lo; g.p_hi = p_hi;
+    ScopedKernelTimer kt(ctx, "wit_sponge_kernel", 3.0 * (double)(p_hi - p_lo));
+    hipLaunchKernelGGL(wit_sponge_kernel, dim3((unsigned)((p_hi - p_lo + 63) / 64), 3), dim3(64), 0, ctx->stream, g);
+    ZK_HIP(hipGetLastError());
+}
+
 }  // namespace zk
 
 extern "C" {
@@ -230,7 +394,8 @@ int zkg16_matrix_sponge_states(size_t n, const uint64_t *a, const uint64_t *b, u
     if (!a || !b || !hashes || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
     try {
         MatrixChains mc;
-        run_chains(mc, n, a, b);
+        mc.start(n, a, b, true);
+        mc.join();
         for (int h = 0; h < 3; h++) {
             memcpy(hashes + 4 * h, mc.hash[h].l, 32);
             if (states) memcpy(states + (size_t)h * mc.perms * 12, mc.states[h].data(), mc.perms * 96);
@@ -249,84 +414,59 @@ int zkg16_witness_matrix(zkg16_ctx *ctx, size_t n, const uint64_t *a, const uint
     if (!a || !b || !witness_handle || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
     if (!ctx) return ZKG16_ERR_BAD_ARG;
     const auto t_call = std::chrono::steady_clock::now();
-    const MatrixWitnessLayout L(n);
-    if (L.total >= ((size_t)1 << 32)) return ZKG16_ERR_DOMAIN_TOO_LARGE;
+    if (MatrixWitnessLayout(n).total >= ((size_t)1 << 32)) return ZKG16_ERR_DOMAIN_TOO_LARGE;
     // the chains need neither the ctx nor the device: they run before the ctx is locked, so that other callers of this ctx are
-    // not held up by ~0.1 s of host arithmetic
-    MatrixChains mc;
+    // not held up by the host arithmetic
+    std::unique_ptr<MatrixWitnessStream, void (*)(MatrixWitnessStream *)> ms(nullptr, matrix_stream_free);
     try {
-        run_chains(mc, n, a, b);
+        ms.reset(matrix_stream_start(n, a, b, 1, false));
+        ms->mc.join();
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
         ZK_HIP(hipSetDevice(ctx->device));
-        if (!ctx->poseidon_dev.p) {
-            const PoseidonH &ph = pparams();
-            PoseidonDev pd;
-            static_assert(sizeof(PoseidonDev) == sizeof(Fr64) * (9 + 3 * P_ROUNDS), "layout");
-            memcpy(pd.mds, ph.mds, sizeof pd.mds);
-            memcpy(pd.ark, ph.ark, sizeof pd.ark);
-            ctx->poseidon_dev.alloc(sizeof pd);
-            ZK_HIP(hipMemcpy(ctx->poseidon_dev.p, &pd, sizeof pd, hipMemcpyHostToDevice));
-        }
         auto w = std::make_unique<WitnessDev>();
-        w->n = L.total;
-        w->z.alloc(L.total * sizeof(Fr));
-        Fr *z = w->z.as<Fr>();
-        DevBuf d_ab(2 * L.nn * sizeof(uint64_t)), d_states(3 * mc.perms * 3 * sizeof(Fr));
+        w->n = ms->L.total;
+        w->z.alloc(ms->L.total * sizeof(Fr));
         hipEvent_t e0, e1;
         ZK_HIP(hipEventCreate(&e0));
         ZK_HIP(hipEventCreate(&e1));
         struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
         ZK_HIP(hipEventRecord(e0, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(d_ab.p, a, L.nn * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(d_ab.as<uint64_t>() + L.nn, b, L.nn * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        for (int h = 0; h < 3; h++)
-            ZK_HIP(hipMemcpyAsync(d_states.as<Fr>() + (size_t)h * 3 * mc.perms, mc.states[h].data(), 3 * mc.perms * sizeof(Fr), hipMemcpyHostToDevice,
-                                  ctx->stream));
-        Fr inst[3];
-        for (int h = 0; h < 3; h++) memcpy(inst[h].l, mc.hash[h].l, 32);
-        ZK_HIP(hipMemcpyAsync(z + 1, inst, sizeof inst, hipMemcpyHostToDevice, ctx->stream));
-        {
-            FillArgs g;
-            g.a = d_ab.as<uint64_t>(); g.b = g.a + L.nn; g.z = z; g.n = n; g.nn = L.nn;
-            g.off_a = L.off_a; g.off_mc = L.off_mc; g.off_mm = L.off_mm; g.total = 3 * L.nn + L.nn * (n + 1);
-            ScopedKernelTimer kt(ctx, "wit_matrix_fill_kernel", (double)g.total);
-            hipLaunchKernelGGL(wit_matrix_fill_kernel, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, ctx->stream, g);
-            ZK_HIP(hipGetLastError());
-        }
-        {
-            SpongeArgs g;
-            for (int h = 0; h < 3; h++) g.states[h] = d_states.as<Fr>() + (size_t)h * 3 * mc.perms;
-            g.out[0] = z + L.off_ha; g.out[1] = z + L.off_hb; g.out[2] = z + L.off_hc;
-            g.params = ctx->poseidon_dev.as<PoseidonDev>();
-            g.p_lo = 0; g.p_hi = (uint32_t)mc.perms;
-            ScopedKernelTimer kt(ctx, "wit_sponge_kernel", 3.0 * (double)mc.perms);
-            hipLaunchKernelGGL(wit_sponge_kernel, dim3((unsigned)((mc.perms + 63) / 64), 3), dim3(64), 0, ctx->stream, g);
-            ZK_HIP(hipGetLastError());
-        }
+        const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
+        auto lap = [&](const char *what) {
+            if (trace) fprintf(stderr, "witness_matrix: %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+        };
+        lap("locked, z allocated");
+        matrix_stream_attach(ms.get(), ctx, w->z.as<Fr>(), 0);
+        lap("attached");
+        matrix_stream_produce(ms.get(), ctx, 0);
+        lap("part 0 queued");
+        matrix_stream_produce(ms.get(), ctx, 1);
+        lap("part 1 queued");
         ZK_HIP(hipEventRecord(e1, ctx->stream));
-        ZK_HIP(hipStreamSynchronize(ctx->stream));      // inst / the chains' vectors are read by the copies above
+        ZK_HIP(hipStreamSynchronize(ctx->stream));      // the copies above read the stream object's host buffers
         float dev_ms = 0;
         ZK_HIP(hipEventElapsedTime(&dev_ms, e0, e1));
-        if (public_inputs)
-            for (int h = 0; h < 3; h++) memcpy(public_inputs + 4 * h, mc.hash[h].l, 32);
+        if (public_inputs) matrix_stream_hashes(ms.get(), public_inputs);
         *witness_handle = ctx->next_handle++;
         ctx->wits[*witness_handle] = std::move(w);
         if (timings_ms) {
-            timings_ms[0] = (float)mc.chain_ms;
+            timings_ms[0] = (float)ms->mc.chain_ms;
             timings_ms[1] = dev_ms;
             timings_ms[2] = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
         }
     } catch (const HipError &e) {
+        (void)hipStreamSynchronize(ctx->stream);
         char buf[512];
         snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.err), e.file, e.line);
         ctx->last_error = buf;
         (void)hipGetLastError();
         return e.err == hipErrorOutOfMemory ? ZKG16_ERR_OOM : ZKG16_ERR_HIP;
     } catch (const std::bad_alloc &) {
+        (void)hipStreamSynchronize(ctx->stream);
         return ZKG16_ERR_OOM;
     }
     return ZKG16_OK;

@@ -161,6 +161,22 @@ class Device:
         self._check(self.lib.zkg16_prove_resident(self.ctx, pk_h, r1cs_h, wit_h, _u64(r), _u64(s), proof, inf))
         return proof, inf
 
+    def prove_matrix(self, pk_h, r1cs_h, a, b, r, s):
+        """One matrix-handler request on resident matrices: assignment built on the device while the proof already runs
+        (zkg16_prove_matrix) -> (proof, inf, public inputs [3, 4], dict of ms)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        n = a.shape[0]
+        if a.shape != (n, n) or b.shape != (n, n):
+            raise ValueError("prove_matrix: a and b must be n x n")
+        proof = np.zeros(48, dtype=np.uint64)
+        inf = np.zeros(3, dtype=np.uint8)
+        pub = np.zeros((3, 4), dtype=np.uint64)
+        ms = (C.c_float * 3)()
+        self._check(self.lib.zkg16_prove_matrix(self.ctx, pk_h, r1cs_h, n, a.reshape(-1), b.reshape(-1), _u64(r), _u64(s), proof, inf,
+                                                pub.ctypes.data, C.addressof(ms)))
+        return proof, inf, pub, dict(host_sponges_ms=float(ms[0]), parts=int(ms[1]), call_ms=float(ms[2]))
+
     def prove(self, pk_h, r, s, r1cs, z):
         args, keep = self._csr(r1cs)
         z = _u64(z).reshape(-1, 4)
