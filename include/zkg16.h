@@ -22,8 +22,11 @@
  * Every entry point returns a zkg16_status; nothing aborts or unwinds across this boundary.
  * A ctx is bound to ONE GPU (one process per GPU; multi-GPU = one ctx per rank + zkg16_prove_partial /
  * zkg16_prove_finish around a single all-gather of 5 partial points).
- * Calls on one ctx are serialised by an internal mutex (actix workers may call concurrently:
- * src/main.rs:37-43); pk / r1cs / witness handles are immutable after load.
+ * A ctx is re-entrant (actix workers call prove concurrently: src/main.rs:37-43): the proving entry points run on "lanes" — up to
+ * option "lanes" (default 2) proofs at a time, each with its own streams and workspaces, all on the SAME resident key, window tables,
+ * matrices and NTT tables (callers beyond that wait); a single caller always gets lane 0 and sees no difference.  Everything else
+ * is serialised by the ctx mutex.  pk / r1cs / witness handles are immutable after load; freeing one while a proof on another lane
+ * still uses it is safe (the memory goes back when that proof ends).
  */
 #ifndef ZKG16_H
 #define ZKG16_H
@@ -293,6 +296,9 @@ ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
 ZKG16_API int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]);
 /* G1 accumulation waves per SIMD (2 or 4) the last proof's term lists ran at: [0] z list, [1] B list, [2] h list; 0 = not built. */
 ZKG16_API int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]);
+/* The lanes of the most recent proofs: rows of (lane, start ms, end ms) on the host's steady clock, oldest first; returns the number of
+ * rows written (<= cap_rows).  Two rows with different lanes and intersecting intervals = two proofs in flight at once. */
+ZKG16_API int zkg16_lane_log(zkg16_ctx *ctx, double *rows, int cap_rows);
 /* Live HIP-event timing of individual kernels (bench.py's roofline leg).  enable: 0 off, 1 every kernel family, 2 only the
  * bucket-accumulation launches (five event pairs per proof instead of ~60).  stats are accumulated per kernel name since
  * the last reset. */
@@ -310,6 +316,7 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
  *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
+ *   "lanes"          proofs this ctx runs at a time (1..8, default 2): see the note on re-entrancy at the top
  *   "matrix_parts"   zkg16_prove_matrix: slices of the host sponges the proof is fed in (0 = five growing slices, k = k equal ones; 1 = assignment first, then the proof)
  * Unknown names return ZKG16_ERR_UNSUPPORTED. */
 ZKG16_API int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value);

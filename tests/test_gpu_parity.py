@@ -702,30 +702,69 @@ def test_sharding_with_empty_shards(dev, oracle, shards):
 
 
 def test_concurrent_callers_on_one_ctx(dev, oracle):
-    """actix runs one worker per core and each may call prove (src/main.rs:37-43): calls on one ctx are serialised by its
-    mutex and every caller gets the right proof."""
+    """actix runs one worker per core and each may call prove (src/main.rs:37-43): a ctx runs two proofs at a time on two lanes
+    that SHARE the resident key, matrices and assignment (option "lanes"); every caller gets the right proof (== the oracle's),
+    proofs on different lanes really overlap (zkg16_lane_log), with lanes = 1 everything is serialised on lane 0, and freeing the
+    handles while proofs are in flight is safe."""
     import threading
     rng = random.Random(5)
-    A, B, C, z = synth.random_r1cs(rng, 500, 3, 400)
-    r1cs = synth.r1cs_arrays(A, B, C, 3)
-    pk, _ = synth.make_pk(oracle, r1cs, 400, rng, point_gen=dev.fixed_base)
+    nc, ni, nv = 20000, 3, 15000
+    A, B, C, z = synth.random_r1cs(rng, nc, ni, nv)
+    r1cs = synth.r1cs_arrays(A, B, C, ni)
+    pk, _ = synth.make_pk(oracle, r1cs, nv, rng, point_gen=dev.fixed_base)
     zm = fr_mont_vec(z)
-    ph, rh, wh = dev.pk_load(pk, 3), dev.r1cs_load(r1cs, 400), dev.witness_load(zm)
-    jobs = [(fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))) for _ in range(6)]
+    ph, rh, wh = dev.pk_load(pk, ni), dev.r1cs_load(r1cs, nv), dev.witness_load(zm)
+    jobs = [(fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))) for _ in range(12)]
+    want = [oracle.prove(pk, r, s, r1cs, zm) for r, s in jobs]
     out = [None] * len(jobs)
 
     def work(i):
         out[i] = dev.prove_resident(ph, rh, wh, *jobs[i])
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+
+    def run_all():
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(len(jobs)):
+            assert np.array_equal(out[i][0], want[i][0]) and np.array_equal(out[i][1], want[i][1]), i
+        return dev.lane_log(len(jobs))
+
+    dev.prove_resident(ph, rh, wh, *jobs[0])                      # warm both the lazy structures and lane 0
+    log = run_all()
+    assert len(log) == len(jobs) and {l for l, _, _ in log} == {0, 1}, log
+    both = [(a, b) for a in log for b in log if a[0] == 0 and b[0] == 1 and a[1] < b[2] and b[1] < a[2]]
+    assert both, "no two proofs on different lanes overlapped: %s" % (log,)
+    dev.set_option("lanes", 1)
+    try:
+        log1 = run_all()
+        assert {l for l, _, _ in log1} == {0}
+        assert all(log1[i][2] <= log1[i + 1][1] + 1e-3 for i in range(len(log1) - 1)), "lanes = 1 must serialise"
+    finally:
+        dev.set_option("lanes", 2)
+    # handles freed under running proofs: the proofs in flight keep their key / matrices / assignment alive
+    started = threading.Event()
+
+    def late(i):
+        started.set()
+        try:
+            out[i] = dev.prove_resident(ph, rh, wh, *jobs[i])
+        except Exception as e:          # noqa: BLE001 - a caller that arrives after the free gets BAD_HANDLE, never a crash
+            out[i] = e
+    ts = [threading.Thread(target=late, args=(i,)) for i in range(4)]
     for t in ts:
         t.start()
+    started.wait()
+    for f, hnd in ((dev.witness_free, wh), (dev.r1cs_free, rh), (dev.pk_free, ph)):
+        f(hnd)
     for t in ts:
         t.join()
-    for i, (r, s) in enumerate(jobs):
-        eproof, einf = oracle.prove(pk, r, s, r1cs, zm)
-        assert np.array_equal(out[i][0], eproof) and np.array_equal(out[i][1], einf)
-    for f, hnd in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
-        f(hnd)
+    for i in range(4):
+        if isinstance(out[i], Exception):
+            assert "handle" in str(out[i])
+        else:
+            assert np.array_equal(out[i][0], want[i][0])
 
 
 def test_prove_prime_like_bits_workload(dev, oracle):

@@ -72,11 +72,134 @@ int fail(zkg16_ctx *ctx, const HipError &e) {
     catch (const std::bad_alloc &) { return ZKG16_ERR_OOM; } \
     return ZKG16_OK;
 
-template <class T>
-T *find_handle(std::map<uint64_t, std::unique_ptr<T>> &m, uint64_t h) {
-    auto it = m.find(h);
-    return it == m.end() ? nullptr : it->second.get();
+// ---- lanes (common.hpp: zkg16_ctx::lanes).  Proving entry points take a free lane for the duration of the call; everything
+// else (key / matrix / assignment residency, setup, the stage entry points) runs on the root under its mutex, as before.
+void copy_options(zkg16_ctx *dst, const zkg16_ctx *src) {
+    dst->opt_window_bits = src->opt_window_bits; dst->opt_min_seg = src->opt_min_seg; dst->opt_ntt_mode = src->opt_ntt_mode;
+    dst->opt_reduce_mode = src->opt_reduce_mode; dst->opt_b_filter = src->opt_b_filter; dst->opt_spmv_dict = src->opt_spmv_dict;
+    dst->opt_wm_first = src->opt_wm_first; dst->opt_g1_waves = src->opt_g1_waves; dst->opt_fixup_aux = src->opt_fixup_aux;
+    dst->opt_window_bits_h = src->opt_window_bits_h; dst->opt_reduce_chunk = src->opt_reduce_chunk; dst->opt_wm_concurrent = src->opt_wm_concurrent;
+    dst->opt_ntt_radix = src->opt_ntt_radix; dst->opt_ntt_xcd = src->opt_ntt_xcd; dst->opt_acc_debug = src->opt_acc_debug;
+    dst->opt_sort_mode = src->opt_sort_mode; dst->opt_acc_pipeline = src->opt_acc_pipeline; dst->opt_fuse_pointwise = src->opt_fuse_pointwise;
+    dst->opt_matrix_parts = src->opt_matrix_parts;
+    dst->kernel_timing = src->kernel_timing; dst->kernel_timing_accumulate_only = src->kernel_timing_accumulate_only;
 }
+void create_streams(zkg16_ctx *ctx) {
+    // Plain (equal-priority) streams.  Measured at n = 32: main low / witness-map high priority 16.6 ms per proof,
+    // reversed 16.2 ms, no priorities 15.0 ms (profiles/kernel_timeline_r1_*.txt).
+    ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ZK_HIP(hipStreamCreateWithFlags(&ctx->wm_stream, hipStreamNonBlocking));
+    // HIP hands streams to its 4 hardware queues round-robin in creation order, and which streams end up sharing a queue
+    // moves a proof by ~4 % (13.9 vs 14.5 ms at n = 32).  All of a ctx's streams are therefore created here, in the order
+    // the measured-best pairing needs (main | witness map | B2, L, A, B1, H reductions).  (A further ctx of the same
+    // process starts three queues on; two such contexts together measured 76 proofs/s, two aligned ones 73.)
+    for (int i : {0, 2, 3, 4, 1}) ZK_HIP(hipStreamCreateWithFlags(&ctx->slots[i].stream, hipStreamNonBlocking));
+}
+// everything a ctx (root or lane) owns on the device
+void teardown(zkg16_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->wm_stream);
+    if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage_host[i]) (void)hipHostFree(ctx->stage_host[i]);
+        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    }
+    for (auto &sl : ctx->slots) {
+        if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
+        if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
+        if (sl.red_done) (void)hipEventDestroy(sl.red_done);
+        if (sl.acc_start) (void)hipEventDestroy(sl.acc_start);
+        if (sl.red_start) (void)hipEventDestroy(sl.red_start);
+        sl.buckets.release();
+        sl.bucket_sum.release();
+        sl.wsums_dev.release();
+        sl.seg_head.release();
+        sl.seg_tail.release();
+        sl.seg_meta.release();
+        sl.long_list.release();
+        sl.long_sums.release();
+        sl.red_a.release(); sl.red_b.release(); sl.red_c.release();
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+    }
+    if (ctx->wm_stream) (void)hipStreamDestroy(ctx->wm_stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+}
+// A free lane of `root` for one proof: the lowest free one (a single caller always gets lane 0 = the root itself, so nothing
+// changes for it); callers beyond opt_lanes wait.  The lane's mutex is held for the lease.
+struct LaneLease {
+    zkg16_ctx *root, *lane = nullptr;
+    int idx = -1;
+    double t0 = 0;
+    std::unique_lock<std::mutex> held;
+    std::shared_lock<std::shared_mutex> keys;
+    explicit LaneLease(zkg16_ctx *r) : root(r) {
+        {
+            std::unique_lock<std::mutex> lk(root->lane_mu);
+            const int cap = root->opt_lanes < 1 ? 1 : root->opt_lanes > 8 ? 8 : root->opt_lanes;
+            root->lane_cv.wait(lk, [&] {
+                for (int i = 0; i < cap; i++)
+                    if (!root->lane_busy[i]) { idx = i; return true; }
+                return false;
+            });
+            if (idx > 0 && (int)root->lanes.size() < idx) root->lanes.resize(idx);
+            if (idx > 0 && !root->lanes[idx - 1]) {
+                ZK_HIP(hipSetDevice(root->device));
+                auto l = std::make_unique<zkg16_ctx>();
+                l->device = root->device;
+                l->num_cus = root->num_cus;
+                l->root = root;
+                copy_options(l.get(), root);
+                try {
+                    create_streams(l.get());
+                } catch (...) {
+                    teardown(l.get());
+                    throw;
+                }
+                root->lanes[idx - 1] = std::move(l);
+            }
+            root->lane_busy[idx] = true;
+            lane = idx == 0 ? root : root->lanes[idx - 1].get();
+        }
+        held = std::unique_lock<std::mutex>(lane->mu);
+        keys = std::shared_lock<std::shared_mutex>(root->key_rw);
+        t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    ~LaneLease() {
+        if (idx < 0) return;
+        const double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (keys.owns_lock()) keys.unlock();
+        if (held.owns_lock()) held.unlock();
+        {
+            std::lock_guard<std::mutex> lk(root->lane_mu);
+            root->lane_busy[idx] = false;
+            root->last_lane = idx;
+            if (root->lane_log.size() >= 256) root->lane_log.erase(root->lane_log.begin(), root->lane_log.begin() + 128);
+            root->lane_log.push_back(zkg16_ctx::LaneLogEntry{idx, t0, t1});
+        }
+        root->lane_cv.notify_one();
+    }
+    LaneLease(const LaneLease &) = delete;
+    LaneLease &operator=(const LaneLease &) = delete;
+};
+zkg16_ctx *lane_of(zkg16_ctx *root, int idx) { return idx <= 0 || idx > (int)root->lanes.size() || !root->lanes[idx - 1] ? root : root->lanes[idx - 1].get(); }
+// the proving entry points: `ctx` is rebound to the leased lane for the body, `root` keeps the handle maps
+#define ZK_LANE_BEGIN(ctx)                        \
+    if (!(ctx)) return ZKG16_ERR_BAD_ARG;         \
+    zkg16_ctx *const root = (ctx);                \
+    try {                                         \
+        LaneLease _lease(root);                   \
+        (ctx) = _lease.lane;                      \
+        try {                                     \
+            ZK_HIP(hipSetDevice((ctx)->device));
+#define ZK_LANE_END(ctx)                          \
+        } catch (const HipError &e) {             \
+            const int _rc = fail((ctx), e);       \
+            if ((ctx) != root) { std::lock_guard<std::mutex> _l(root->lane_mu); root->last_error = (ctx)->last_error; } \
+            return _rc;                           \
+        }                                         \
+    } catch (const HipError &e) { return fail(root, e); } \
+    catch (const std::bad_alloc &) { return ZKG16_ERR_OOM; } \
+    return ZKG16_OK;
 
 // ---- host <-> ABI point conversions (u64 limbs and u32 limbs share the little-endian byte layout)
 G1Affine g1_from_abi(const uint64_t *l, int inf) {
@@ -576,7 +699,7 @@ int load_r1cs(zkg16_ctx *ctx, const uint64_t *const rp[3], const uint32_t *const
     r1cs_copy(ctx, *r, rp, col, cf);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     *handle = ctx->next_handle++;
-    ctx->r1cs[*handle] = std::move(r);
+    ctx->r1cs.put(*handle, std::move(r));
     return ZKG16_OK;
 }
 
@@ -641,15 +764,7 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
             delete ctx;
             return ZKG16_ERR_NO_DEVICE;
         }
-        // Plain (equal-priority) streams.  Measured at n = 32: main low / witness-map high priority 16.6 ms per proof,
-        // reversed 16.2 ms, no priorities 15.0 ms (profiles/kernel_timeline_r1_*.txt).
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->wm_stream, hipStreamNonBlocking));
-        // HIP hands streams to its 4 hardware queues round-robin in creation order, and which streams end up sharing a queue
-        // moves a proof by ~4 % (13.9 vs 14.5 ms at n = 32).  All of a ctx's streams are therefore created here, in the order
-        // the measured-best pairing needs (main | witness map | B2, L, A, B1, H reductions).  (A further ctx of the same
-        // process starts three queues on; two such contexts together measured 76 proofs/s, two aligned ones 73.)
-        for (int i : {0, 2, 3, 4, 1}) ZK_HIP(hipStreamCreateWithFlags(&ctx->slots[i].stream, hipStreamNonBlocking));
+        create_streams(ctx);
     } catch (const HipError &e) {
         int rc = fail(ctx, e);
         delete ctx;
@@ -662,42 +777,24 @@ int zkg16_init(const int *device_ids, int n_devices, zkg16_ctx **out) {
 void zkg16_destroy(zkg16_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->wm_stream);
-    if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->stage_host[i]) (void)hipHostFree(ctx->stage_host[i]);
-        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
-    }
-    for (auto &sl : ctx->slots) {
-        if (sl.wsums_host) (void)hipHostFree(sl.wsums_host);
-        if (sl.acc_done) (void)hipEventDestroy(sl.acc_done);
-        if (sl.red_done) (void)hipEventDestroy(sl.red_done);
-        if (sl.acc_start) (void)hipEventDestroy(sl.acc_start);
-        if (sl.red_start) (void)hipEventDestroy(sl.red_start);
-        sl.buckets.release();
-        sl.wsums_dev.release();
-        sl.seg_head.release();
-        sl.seg_tail.release();
-        sl.seg_meta.release();
-        sl.long_list.release();
-        sl.long_sums.release();
-        sl.red_a.release(); sl.red_b.release(); sl.red_c.release();
-        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
-    }
+    for (auto &l : ctx->lanes)
+        if (l) {
+            std::lock_guard<std::mutex> lk(l->mu);      // a proof still running on that lane finishes first
+            teardown(l.get());
+        }
+    ctx->lanes.clear();
+    teardown(ctx);
     ctx->pks.clear();
     ctx->r1cs.clear();
     ctx->wits.clear();
     ctx->ntt_tables.clear();
-    (void)hipStreamDestroy(ctx->wm_stream);
-    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     dev_cache_flush();      // a destroyed ctx really returns its memory (other live contexts simply allocate afresh)
 }
 
-int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
-    if (!ctx || !name) return ZKG16_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+}  // extern "C"
+namespace {
+int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "window_bits")) {
         if (value != 0 && (value < 2 || value > 20)) return ZKG16_ERR_BAD_ARG;
         ctx->opt_window_bits = (int)value;
@@ -794,6 +891,37 @@ int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
     }
     return ZKG16_ERR_UNSUPPORTED;
 }
+}  // namespace
+extern "C" {
+
+// Options apply to every lane of the ctx (a lane created later copies the root's).  "lanes": proofs this ctx runs at a time
+// (1..8, default 2; callers beyond that wait).
+int zkg16_set_option(zkg16_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return ZKG16_ERR_BAD_ARG;
+    if (!strcmp(name, "lanes")) {
+        if (value < 1 || value > 8) return ZKG16_ERR_BAD_ARG;
+        std::lock_guard<std::mutex> lk(ctx->lane_mu);
+        ctx->opt_lanes = (int)value;
+        return ZKG16_OK;
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        rc = set_option_one(ctx, name, value);
+    }
+    if (rc != ZKG16_OK) return rc;
+    std::vector<zkg16_ctx *> ls;
+    {
+        std::lock_guard<std::mutex> lk(ctx->lane_mu);
+        for (auto &l : ctx->lanes)
+            if (l) ls.push_back(l.get());
+    }
+    for (zkg16_ctx *l : ls) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        (void)set_option_one(l, name, value);
+    }
+    return ZKG16_OK;
+}
 
 int zkg16_pk_load_range(zkg16_ctx *ctx,
                         const uint64_t *a_query, const uint8_t *a_inf, size_t n_a,
@@ -851,7 +979,7 @@ int zkg16_pk_load_range(zkg16_ctx *ctx,
     pk->b_mask.alloc(nz + 3);
     pk->b_skipped = b_density_mask_run(ctx, pk->b1.as<G1AffineU>(), pk->b2.as<G2AffineU>(), nz + 3, pk->b_mask.as<uint8_t>());
     *pk_handle = ctx->next_handle++;
-    ctx->pks[*pk_handle] = std::move(pk);
+    ctx->pks.put(*pk_handle, std::move(pk));
     ZK_API_END(ctx)
 }
 
@@ -878,7 +1006,7 @@ int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t src_handle, size_t z_lo, size_t z_hi
                    uint64_t *pk_handle) {
     if (!pk_handle) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    PkDev *src = find_handle(ctx->pks, src_handle);
+    auto src_ref = ctx->pks.get(src_handle); PkDev *src = src_ref.get();
     if (!src) return ZKG16_ERR_BAD_HANDLE;
     if (!src->full) return ZKG16_ERR_BAD_ARG;
     if (z_lo > z_hi || z_hi > src->m_total || h_lo > h_hi || h_hi > src->n_h_total) return ZKG16_ERR_BAD_ARG;
@@ -910,7 +1038,7 @@ int zkg16_pk_slice(zkg16_ctx *ctx, uint64_t src_handle, size_t z_lo, size_t z_hi
     pk->b_mask.alloc(nz + 3);
     pk->b_skipped = b_density_mask_run(ctx, pk->b1.as<G1AffineU>(), pk->b2.as<G2AffineU>(), nz + 3, pk->b_mask.as<uint8_t>());
     *pk_handle = ctx->next_handle++;
-    ctx->pks[*pk_handle] = std::move(pk);
+    ctx->pks.put(*pk_handle, std::move(pk));
     ZK_API_END(ctx)
 }
 
@@ -1040,7 +1168,8 @@ int zkg16_pk_precompute(zkg16_ctx *ctx, uint64_t pk_handle, int window_bits_z, i
     if (window_bits_z > 24 || window_bits_h > 24 || (window_bits_z > 0 && window_bits_z < 4) || (window_bits_h > 0 && window_bits_h < 4))
         return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    std::unique_lock<std::shared_mutex> keys(ctx->key_rw);      // the key's buffers are replaced: no proof on any lane meanwhile
+    auto pk_ref = ctx->pks.get(pk_handle); PkDev *pk = pk_ref.get();
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
     if ((window_bits_z >= 0 && pk->tab_c_z) || (window_bits_h >= 0 && pk->tab_c_h)) return ZKG16_ERR_BAD_ARG;      // already built
     const size_t nz = pk->z_hi - pk->z_lo, nzs = nz + 3, nh = pk->h_hi - pk->h_lo;
@@ -1068,7 +1197,7 @@ int zkg16_pk_precompute(zkg16_ctx *ctx, uint64_t pk_handle, int window_bits_z, i
 
 int zkg16_pk_table_bits(zkg16_ctx *ctx, uint64_t pk_handle, int *window_bits_z, int *window_bits_h) {
     ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    auto pk_ref = ctx->pks.get(pk_handle); PkDev *pk = pk_ref.get();
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
     if (window_bits_z) *window_bits_z = pk->tab_c_z;
     if (window_bits_h) *window_bits_h = pk->tab_c_h;
@@ -1112,7 +1241,7 @@ int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n
     ZK_HIP(hipMemcpyAsync(w->z.p, full_assignment, n_assign * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     *witness_handle = ctx->next_handle++;
-    ctx->wits[*witness_handle] = std::move(w);
+    ctx->wits.put(*witness_handle, std::move(w));
     ZK_API_END(ctx)
 }
 
@@ -1121,7 +1250,7 @@ int zkg16_witness_load(zkg16_ctx *ctx, const uint64_t *full_assignment, size_t n
 int zkg16_witness_read(zkg16_ctx *ctx, uint64_t witness_handle, uint64_t *out, size_t n_assign) {
     if (!out) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    WitnessDev *w = find_handle(ctx->wits, witness_handle);
+    auto w_ref = ctx->wits.get(witness_handle); WitnessDev *w = w_ref.get();
     if (!w) return ZKG16_ERR_BAD_HANDLE;
     if (w->n != n_assign) return ZKG16_ERR_BAD_ARG;
     ZK_HIP(hipMemcpyAsync(out, w->z.p, n_assign * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
@@ -1139,10 +1268,10 @@ void zkg16_witness_free(zkg16_ctx *ctx, uint64_t h) {
 int zkg16_prove_partial(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
                         const uint64_t r[4], const uint64_t s[4], uint64_t partial_out[72], uint8_t partial_inf[5]) {
     if (!r || !s || !partial_out || !partial_inf) return ZKG16_ERR_BAD_ARG;
-    ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
-    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    ZK_LANE_BEGIN(ctx)
+    auto pk_ref = root->pks.get(pk_handle); PkDev *pk = pk_ref.get();
+    auto rc_ref = root->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
+    auto wit_ref = root->wits.get(witness_handle); WitnessDev *wit = wit_ref.get();
     if (!pk || !rc || !wit) return ZKG16_ERR_BAD_HANDLE;
     if (wit->n != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != rc->num_instance ||
         pk->n_h_total != ((size_t)1 << rc->log_n) - 1)
@@ -1154,14 +1283,14 @@ int zkg16_prove_partial(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle
     point_to_abi(xyzz_to_affine(p.a), partial_out + 24, partial_inf + 2);
     point_to_abi(xyzz_to_affine(p.b1), partial_out + 36, partial_inf + 3);
     point_to_abi(xyzz_to_affine(p.b2), partial_out + 48, partial_inf + 4);
-    ZK_API_END(ctx)
+    ZK_LANE_END(ctx)
 }
 
 int zkg16_prove_finish(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
                        const uint64_t *partials, const uint8_t *partial_inf, int n_ranks, uint64_t proof_out[48], uint8_t inf_out[3]) {
     if (!r || !s || !partials || !partial_inf || n_ranks < 1 || !proof_out || !inf_out) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    auto pk_ref = ctx->pks.get(pk_handle); PkDev *pk = pk_ref.get();
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
     Partials p;
     sum_partials(p, partials, partial_inf, n_ranks);
@@ -1184,10 +1313,10 @@ int zkg16_combine_partials(const uint64_t alpha_g1[12], const uint64_t beta_g1[1
 int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle, uint64_t witness_handle,
                          const uint64_t r[4], const uint64_t s[4], uint64_t proof_out[48], uint8_t inf_out[3]) {
     if (!r || !s || !proof_out || !inf_out) return ZKG16_ERR_BAD_ARG;
-    ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
-    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    ZK_LANE_BEGIN(ctx)
+    auto pk_ref = root->pks.get(pk_handle); PkDev *pk = pk_ref.get();
+    auto rc_ref = root->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
+    auto wit_ref = root->wits.get(witness_handle); WitnessDev *wit = wit_ref.get();
     if (!pk || !rc || !wit) return ZKG16_ERR_BAD_HANDLE;
     if (!pk->full) return ZKG16_ERR_BAD_ARG;                            // sharded keys go through prove_partial/finish
     if (wit->n != rc->num_variables || pk->m_total != rc->num_variables || pk->num_instance != rc->num_instance ||
@@ -1200,7 +1329,7 @@ int zkg16_prove_resident(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handl
     prove_tail(*pk, rr, ss, p, proof_out, inf_out);
     ctx->timings[8] = (float)(now_ms() - t0);
     ctx->timings[9] += ctx->timings[8];
-    ZK_API_END(ctx)
+    ZK_LANE_END(ctx)
 }
 
 // One MatrixCircuit request on matrices that are already resident: what the reference times as `proving_time`
@@ -1221,9 +1350,9 @@ int zkg16_prove_matrix(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle,
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
-    ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    ZK_LANE_BEGIN(ctx)
+    auto pk_ref = root->pks.get(pk_handle); PkDev *pk = pk_ref.get();
+    auto rc_ref = root->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
     if (!pk || !rc) return ZKG16_ERR_BAD_HANDLE;
     if (!pk->full) return ZKG16_ERR_BAD_ARG;
     const size_t total = matrix_stream_total(ms.get());
@@ -1254,7 +1383,7 @@ int zkg16_prove_matrix(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1cs_handle,
         timings_ms[1] = (float)zp.parts;
         timings_ms[2] = (float)(now_ms() - t_call);
     }
-    ZK_API_END(ctx)
+    ZK_LANE_END(ctx)
 }
 
 int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const uint64_t s[4],
@@ -1264,8 +1393,8 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
                 size_t num_instance, size_t num_constraints, const uint64_t *full_assignment, size_t n_assign,
                 uint64_t proof_out[48], uint8_t inf_out[3]) {
     if (!r || !s || !proof_out || !inf_out || !full_assignment || n_assign == 0) return ZKG16_ERR_BAD_ARG;
-    ZK_API_BEGIN(ctx)
-    PkDev *pk = find_handle(ctx->pks, pk_handle);
+    ZK_LANE_BEGIN(ctx)
+    auto pk_ref = root->pks.get(pk_handle); PkDev *pk = pk_ref.get();
     if (!pk) return ZKG16_ERR_BAD_HANDLE;
     if (!pk->full) return ZKG16_ERR_BAD_ARG;
     const uint64_t *rp[3] = {a_row_ptr, b_row_ptr, c_row_ptr};
@@ -1289,7 +1418,7 @@ int zkg16_prove(zkg16_ctx *ctx, uint64_t pk_handle, const uint64_t r[4], const u
     prove_tail(*pk, rr, ss, p, proof_out, inf_out);
     ctx->timings[8] = (float)(now_ms() - t0);
     ctx->timings[9] += ctx->timings[8];
-    ZK_API_END(ctx)
+    ZK_LANE_END(ctx)
 }
 
 int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20], const uint64_t g1_gen[12], const uint64_t g2_gen[24],
@@ -1301,7 +1430,7 @@ int zkg16_setup(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t trapdoor[20
         !delta_g1 || !delta_g2 || !gamma_g2 || !gamma_abc_g1)
         return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    auto rc_ref = ctx->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
     if (!rc) return ZKG16_ERR_BAD_HANDLE;
     Fr trap[5];
     memcpy(trap, trapdoor, sizeof trap);
@@ -1318,7 +1447,7 @@ int zkg16_setup_resident(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t tr
                          uint64_t *gamma_abc_g1) {
     if (!trapdoor || !g1_gen || !g2_gen || !pk_handle || !alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
+    auto rc_ref = ctx->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
     if (!rc) return ZKG16_ERR_BAD_HANDLE;
     Fr trap[5];
     memcpy(trap, trapdoor, sizeof trap);
@@ -1330,7 +1459,7 @@ int zkg16_setup_resident(zkg16_ctx *ctx, uint64_t r1cs_handle, const uint64_t tr
                alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2};
     setup_run(ctx, *rc, trap, g1_from_abi(g1_gen, 0), g2_from_abi(g2_gen, 0), o, pk.get());
     *pk_handle = ctx->next_handle++;
-    ctx->pks[*pk_handle] = std::move(pk);
+    ctx->pks.put(*pk_handle, std::move(pk));
     ZK_API_END(ctx)
 }
 
@@ -1380,8 +1509,8 @@ int zkg16_bench_ntt(zkg16_ctx *ctx, size_t log_n, int inverse, int coset, int it
 int zkg16_bench_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, int iters, float *ms_per_iter) {
     if (!ms_per_iter || iters < 1) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
-    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    auto rc_ref = ctx->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
+    auto wit_ref = ctx->wits.get(witness_handle); WitnessDev *wit = wit_ref.get();
     if (!rc || !wit) return ZKG16_ERR_BAD_HANDLE;
     if (wit->n != rc->num_variables) return ZKG16_ERR_BAD_ARG;
     Fr *h = nullptr;
@@ -1451,8 +1580,8 @@ int zkg16_bench_msm(zkg16_ctx *ctx, int group, const uint64_t *bases, const uint
 int zkg16_witness_map(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t witness_handle, uint64_t *h_out, size_t *log_n_out) {
     if (!h_out) return ZKG16_ERR_BAD_ARG;
     ZK_API_BEGIN(ctx)
-    R1csDev *rc = find_handle(ctx->r1cs, r1cs_handle);
-    WitnessDev *wit = find_handle(ctx->wits, witness_handle);
+    auto rc_ref = ctx->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
+    auto wit_ref = ctx->wits.get(witness_handle); WitnessDev *wit = wit_ref.get();
     if (!rc || !wit) return ZKG16_ERR_BAD_HANDLE;
     if (wit->n != rc->num_variables) return ZKG16_ERR_BAD_ARG;
     Fr *h = nullptr;
@@ -1503,16 +1632,23 @@ int zkg16_fixed_base_g2(zkg16_ctx *ctx, const uint64_t base[24], const uint64_t 
 // ------------------------------------------------------------------------------------------------ instrumentation
 int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap) {
     if (!ctx || !ms) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    int last;
+    { std::lock_guard<std::mutex> lk(ctx->lane_mu); last = ctx->last_lane; }
+    zkg16_ctx *l = lane_of(ctx, last);
+    std::lock_guard<std::mutex> lk(l->mu);
     const int n = cap < 20 ? cap : 20;
-    for (int i = 0; i < n; i++) ms[i] = ctx->timings[i];
+    for (int i = 0; i < n; i++) ms[i] = l->timings[i];
     return n;
 }
 
 // Lengths of the sorted (scalar, window) term lists of the last proof on this ctx = mixed additions per MSM that uses the list:
 // [0] the z list (A and L), [1] the B list (B1 and B2; 0 = they used the z list), [2] the h list.  Synchronises the ctx.
 int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]) {
-    if (!counts) return ZKG16_ERR_BAD_ARG;
+    if (!counts || !ctx) return ZKG16_ERR_BAD_ARG;
+    int last;
+    { std::lock_guard<std::mutex> lk(ctx->lane_mu); last = ctx->last_lane; }
+    zkg16_ctx *root = ctx;
+    ctx = lane_of(root, last);
     ZK_API_BEGIN(ctx)
     ZK_HIP(hipDeviceSynchronize());
     MsmWorkspace *w[3] = {&ctx->ws_z, &ctx->ws_zb, &ctx->ws_h};
@@ -1529,44 +1665,77 @@ int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]) {
 // bucket accumulations actually ran at, which is the row of the bare-loop microbenchmark bench.py must compare them with.
 int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]) {
     if (!ctx || !waves) return ZKG16_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    MsmWorkspace *w[3] = {&ctx->ws_z, &ctx->ws_zb, &ctx->ws_h};
-    for (int i = 0; i < 3; i++) waves[i] = w[i]->last_tb ? (int)(w[i]->last_lanes_g1 / ((uint32_t)ctx->num_cus * 4u * 64u)) : 0;
+    int last;
+    { std::lock_guard<std::mutex> lk(ctx->lane_mu); last = ctx->last_lane; }
+    zkg16_ctx *l = lane_of(ctx, last);
+    std::lock_guard<std::mutex> lk(l->mu);
+    MsmWorkspace *w[3] = {&l->ws_z, &l->ws_zb, &l->ws_h};
+    for (int i = 0; i < 3; i++) waves[i] = w[i]->last_tb ? (int)(w[i]->last_lanes_g1 / ((uint32_t)l->num_cus * 4u * 64u)) : 0;
     return ZKG16_OK;
 }
+
+// the lanes (host intervals, steady-clock ms) of the most recent proofs on this ctx: rows of (lane, start, end); returns the
+// number of rows written.  Two proofs whose intervals intersect on different lanes ran at the same time.
+int zkg16_lane_log(zkg16_ctx *ctx, double *rows, int cap_rows) {
+    if (!ctx || !rows || cap_rows < 0) return 0;
+    std::lock_guard<std::mutex> lk(ctx->lane_mu);
+    const int n = (int)ctx->lane_log.size() < cap_rows ? (int)ctx->lane_log.size() : cap_rows;
+    for (int i = 0; i < n; i++) {
+        const auto &e = ctx->lane_log[ctx->lane_log.size() - n + i];
+        rows[3 * i] = e.lane; rows[3 * i + 1] = e.t0_ms; rows[3 * i + 2] = e.t1_ms;
+    }
+    return n;
+}
+
+namespace {
+std::vector<zkg16_ctx *> all_lanes(zkg16_ctx *root) {
+    std::vector<zkg16_ctx *> v{root};
+    std::lock_guard<std::mutex> lk(root->lane_mu);
+    for (auto &l : root->lanes)
+        if (l) v.push_back(l.get());
+    return v;
+}
+}  // namespace
 
 int zkg16_kernel_timing(zkg16_ctx *ctx, int enable) {
     if (!ctx) return ZKG16_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->kernel_timing = enable != 0;
-    ctx->kernel_timing_accumulate_only = enable == 2;
+    for (zkg16_ctx *l : all_lanes(ctx)) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        l->kernel_timing = enable != 0;
+        l->kernel_timing_accumulate_only = enable == 2;
+    }
     return ZKG16_OK;
 }
 
+// summed over the lanes of the ctx
 int zkg16_kernel_stats(zkg16_ctx *ctx, const char *kernel_name, uint64_t *launches, double *total_ms, double *units) {
     if (!ctx || !kernel_name) return ZKG16_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    (void)hipSetDevice(ctx->device);
-    kernel_timer_resolve(ctx);
-    auto it = ctx->kstats.find(kernel_name);
-    if (it == ctx->kstats.end()) {
-        if (launches) *launches = 0;
-        if (total_ms) *total_ms = 0;
-        if (units) *units = 0;
-        return ZKG16_OK;
+    uint64_t n = 0;
+    double ms = 0, u = 0;
+    for (zkg16_ctx *l : all_lanes(ctx)) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        (void)hipSetDevice(l->device);
+        kernel_timer_resolve(l);
+        auto it = l->kstats.find(kernel_name);
+        if (it == l->kstats.end()) continue;
+        n += it->second.launches;
+        ms += it->second.ms;
+        u += it->second.units;
     }
-    if (launches) *launches = it->second.launches;
-    if (total_ms) *total_ms = it->second.ms;
-    if (units) *units = it->second.units;
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (units) *units = u;
     return ZKG16_OK;
 }
 
 void zkg16_kernel_stats_reset(zkg16_ctx *ctx) {
     if (!ctx) return;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    (void)hipSetDevice(ctx->device);
-    kernel_timer_resolve(ctx);
-    ctx->kstats.clear();
+    for (zkg16_ctx *l : all_lanes(ctx)) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        (void)hipSetDevice(l->device);
+        kernel_timer_resolve(l);
+        l->kstats.clear();
+    }
 }
 
 }  // extern "C"

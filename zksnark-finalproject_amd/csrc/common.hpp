@@ -5,10 +5,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -105,6 +108,7 @@ struct PendingEvent;
 
 struct NttTables {          // per domain size, built on device on first use
     int log_n = 0;
+    std::mutex mu;          // the tables below that are built on first use (g_u / gi_u, wu): lanes of one ctx share this object
     DevBuf w;               // w[j]  = omega_N^j,            j < N
     DevBuf wu;              // the same in the unsaturated form (36 B per entry); only built for N > 2^22
     DevBuf g;               // g[i]  = 7^i                   (coset fft pre-multiply)
@@ -152,9 +156,45 @@ struct R1csDev {
     // the same number of non-zeros.  Built with the dictionary; null = natural order
     DevBuf perm[3];
     bool perm_ok = false;
+    std::mutex lazy_mu;             // the dictionary / row order are built once, by whichever lane gets there first
 };
 
 struct WitnessDev { size_t n = 0; DevBuf z; };
+
+// handle -> resident object.  Objects are shared_ptr: a proof in flight on one lane keeps its key / matrices / assignment alive
+// when another caller frees the handle meanwhile (the memory goes back when that proof ends).
+template <class T>
+class HandleMap {
+    std::mutex mu_;
+    std::map<uint64_t, std::shared_ptr<T>> m_;
+  public:
+    std::shared_ptr<T> get(uint64_t h) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = m_.find(h);
+        return it == m_.end() ? nullptr : it->second;
+    }
+    void put(uint64_t h, std::shared_ptr<T> v) {
+        std::lock_guard<std::mutex> lk(mu_);
+        m_[h] = std::move(v);
+    }
+    void erase(uint64_t h) {
+        std::shared_ptr<T> dying;           // destroyed outside the lock (a DevBuf release synchronises the device)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = m_.find(h);
+            if (it == m_.end()) return;
+            dying = std::move(it->second);
+            m_.erase(it);
+        }
+    }
+    void clear() {
+        std::map<uint64_t, std::shared_ptr<T>> dying;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dying.swap(m_);
+        }
+    }
+};
 
 struct MsmSlot {            // one in-flight MSM: written by the accumulate half (main stream), read by the reduce half (aux)
     DevBuf buckets, wsums_dev, seg_head, seg_tail, seg_meta, long_list, long_sums, red_a, red_b, red_c;
@@ -189,11 +229,27 @@ struct zkg16_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string last_error;
-    std::map<int, std::unique_ptr<zk::NttTables>> ntt_tables;
-    std::map<uint64_t, std::unique_ptr<zk::PkDev>> pks;
-    std::map<uint64_t, std::unique_ptr<zk::R1csDev>> r1cs;
-    std::map<uint64_t, std::unique_ptr<zk::WitnessDev>> wits;
-    uint64_t next_handle = 1;
+    std::map<int, std::unique_ptr<zk::NttTables>> ntt_tables;     // root only (guarded by ntt_mu): lanes share the tables
+    std::mutex ntt_mu;
+    zk::HandleMap<zk::PkDev> pks;                                 // root only
+    zk::HandleMap<zk::R1csDev> r1cs;
+    zk::HandleMap<zk::WitnessDev> wits;
+    std::atomic<uint64_t> next_handle{1};
+    // ---- lanes: a ctx proves up to `opt_lanes` proofs at a time (actix workers call prove concurrently: src/main.rs:37-43).  A
+    // lane is a zkg16_ctx of its own — streams, MSM workspaces and slots, witness-map vectors, pinned buffers — whose `root` is
+    // the ctx the caller holds; keys, matrices, assignments and NTT tables live in the root and are shared (HBM grows by a
+    // lane's workspaces, not by a second copy of the key and its window tables).  Lane 0 is the root itself; further lanes are
+    // created when a second caller arrives while the first is still proving.
+    zkg16_ctx *root = nullptr;
+    std::vector<std::unique_ptr<zkg16_ctx>> lanes;                // root: lanes 1 ..
+    std::mutex lane_mu;
+    std::condition_variable lane_cv;
+    bool lane_busy[8] = {false, false, false, false, false, false, false, false};
+    int opt_lanes = 2;
+    int last_lane = 0;                                            // lane of the proof that finished last (zkg16_last_timings)
+    std::shared_mutex key_rw;                                     // proofs: shared; in-place changes of a resident key (zkg16_pk_precompute): exclusive
+    struct LaneLogEntry { int lane; double t0_ms, t1_ms; };
+    std::vector<LaneLogEntry> lane_log;                           // root (under lane_mu): the last proofs' lanes and host intervals
     zk::MsmWorkspace ws_z, ws_h, ws_zb;               // one workspace per scalar vector (z, h, and z masked by the B-query density)
     hipStream_t wm_stream = nullptr;                  // witness map + h-side sort of a proof, concurrent with the z-side MSMs
     zk::MsmSlot slots[5];                             // B2, H, L, A, B1 of one proof

@@ -454,8 +454,12 @@ static Fr fr_from_u64_host(uint64_t v) {
 }
 
 NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
-    auto it = ctx->ntt_tables.find(log_n);
-    if (it != ctx->ntt_tables.end()) return it->second.get();
+    // the tables belong to the root ctx and are shared by its lanes; the build below ends with a stream synchronisation, so a
+    // table that is in the map is complete for every stream of every lane
+    zkg16_ctx *owner = ctx->root ? ctx->root : ctx;
+    std::lock_guard<std::mutex> lk(owner->ntt_mu);
+    auto it = owner->ntt_tables.find(log_n);
+    if (it != owner->ntt_tables.end()) return it->second.get();
     auto t = std::make_unique<NttTables>();
     t->log_n = log_n;
     const size_t n = (size_t)1 << log_n;
@@ -485,7 +489,7 @@ NttTables *ntt_get_tables(zkg16_ctx *ctx, int log_n) {
     // the tables later without an event between them, so the build is completed here — and only cached once it has succeeded
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     NttTables *raw = t.get();
-    ctx->ntt_tables[log_n] = std::move(t);
+    owner->ntt_tables[log_n] = std::move(t);
     return raw;
 }
 
@@ -527,6 +531,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
         // pre-multiply (a full conversion) or the fused point-wise stage (likewise)
         const bool two_big = ctx->opt_ntt_mode != 3 && log_n > 2 * NTT_MAX_SUB_LOG && log_n <= 24;
         const int passes = log_n <= NTT_MAX_SUB_LOG ? 1 : (two_big || log_n <= 2 * NTT_MAX_SUB_LOG) ? 2 : 3;
+        std::unique_lock<std::mutex> lazy(t->mu);           // lanes share the table object: one of them builds, the others wait
         if (t->u_passes != passes || !t->g_u.p) {
             DevBuf gu(n * sizeof(Fr)), giu(n * sizeof(Fr));
             const Fr g = fr_from_u64_host(7), g_inv = fp_inv(g);
@@ -541,6 +546,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             t->gi_u = std::move(giu);
             t->u_passes = passes;
         }
+        lazy.unlock();
         // (the fused point-wise load is scaled to leave the same 2^-5 as a plain load, so one gi_u table serves both)
         const int deficit = passes - (pre ? 1 : 0);
         Fr back = fr_from_u64_host(1);
@@ -567,6 +573,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
     if (uform && ctx->opt_ntt_mode != 3 && log_n > 2 * NTT_MAX_SUB_LOG && log_n <= 24) {
         // 2^23, 2^24: two passes over 4096-point tiles (N1 = 2^(log_n - 12) columns-first, N2 = 2^12) with the sub-transform
         // twiddles read from a U-form table in global memory, instead of three passes over 2048-point tiles
+        std::unique_lock<std::mutex> lazy(t->mu);
         if (!t->wu.p) {
             DevBuf wu(n * 9 * sizeof(uint32_t));
             hipLaunchKernelGGL(ntt_wu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, t->w.as<Fr>(), wu.as<uint32_t>(), n);
@@ -574,6 +581,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             ZK_HIP(hipStreamSynchronize(ctx->stream));      // first use only: other streams of this ctx may read the table next
             t->wu = std::move(wu);                          // cached only once it is complete
         }
+        lazy.unlock();
         a.wu = t->wu.as<uint32_t>();
         a.log_n2 = 12;
         a.log_n1 = log_n - 12;

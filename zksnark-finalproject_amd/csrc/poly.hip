@@ -376,7 +376,10 @@ static void coef_dict_build(zkg16_ctx *ctx, R1csDev &m) {
 void spmv_run(zkg16_ctx *ctx, R1csDev &m, const Fr *z, Fr *a, Fr *b, Fr *c) {
     // both structures are built the SECOND time a handle is used: the reference's request flow uses its matrices once (the
     // three passes of the build cost more than they save there: Fermat-prime request 8.1 -> 9.7 ms), a resident system pays once
-    if (m.dict_state == 0 && ctx->opt_spmv_dict != 2 && ++m.spmv_uses >= 2) coef_dict_build(ctx, m);
+    {
+        std::lock_guard<std::mutex> lazy(m.lazy_mu);       // lanes share the handle: one of them builds (and synchronises its stream), the others wait
+        if (m.dict_state == 0 && ctx->opt_spmv_dict != 2 && ++m.spmv_uses >= 2) coef_dict_build(ctx, m);
+    }
     const size_t n = (size_t)1 << m.log_n;
     const unsigned grid = (unsigned)((n + 255) / 256);
     ScopedKernelTimer kt(ctx, "spmv_kernel", (double)(m.nnz[0] + m.nnz[1] + m.nnz[2]));

@@ -452,7 +452,7 @@ int zkg16_witness_matrix(zkg16_ctx *ctx, size_t n, const uint64_t *a, const uint
         ZK_HIP(hipEventElapsedTime(&dev_ms, e0, e1));
         if (public_inputs) matrix_stream_hashes(ms.get(), public_inputs);
         *witness_handle = ctx->next_handle++;
-        ctx->wits[*witness_handle] = std::move(w);
+        ctx->wits.put(*witness_handle, std::move(w));
         if (timings_ms) {
             timings_ms[0] = (float)ms->mc.chain_ms;
             timings_ms[1] = dev_ms;

@@ -84,6 +84,12 @@ class Device:
         self._check(self.lib.zkg16_last_term_counts(self.ctx, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def lane_log(self, rows=64):
+        """-> list of (lane, start_ms, end_ms) of the most recent proofs on this ctx (zkg16_lane_log), oldest first."""
+        buf = (C.c_double * (3 * rows))()
+        n = self.lib.zkg16_lane_log(self.ctx, buf, rows)
+        return [(int(buf[3 * i]), float(buf[3 * i + 1]), float(buf[3 * i + 2])) for i in range(n)]
+
     def last_acc_waves(self):
         """-> G1 accumulation waves per SIMD of the last proof's (z, B, h) term lists (zkg16_last_acc_waves); 0 = list not built."""
         out = (C.c_int * 3)()

@@ -32,11 +32,12 @@ class _CachedShape:
         self.num_constraints, self.domain = circ.num_constraints, circ.domain
 
     def instantiate(self, a, b):
-        from .circuits import matrix_witness
+        """The request's circuit without a host assignment: z is built on the device inside the proof (zkg16_prove_matrix)."""
         inst = _CachedShape.__new__(_CachedShape)
         inst.__dict__.update(self.__dict__)
-        inst.z = matrix_witness(a, b, self.num_vars)
-        inst.public_inputs = inst.z[1:self.num_instance].copy()
+        inst.z = None
+        inst.matrices = (a, b)
+        inst.public_inputs = None           # hash_a, hash_b, hash_c come back from the proof call
         inst.r1cs = None
         return inst
 
@@ -58,12 +59,19 @@ def _setup_and_prove(dev, circ, rng, keep_key=False):
         pk = None
         ph, vk = dev.setup_resident(rh, circ.num_instance, trap, g1, g2)
     setup_time = time.perf_counter() - t0
-    wh = dev.witness_load(circ.z)
     r, s = _fr_mont(rng.randrange(R_MOD)), _fr_mont(rng.randrange(R_MOD))
-    t0 = time.perf_counter()
-    proof, inf = dev.prove_resident(ph, rh, wh, r, s)
-    proving_time = time.perf_counter() - t0
-    for f, h in ((dev.pk_free, ph), (dev.witness_free, wh)) + (() if cached else ((dev.r1cs_free, rh),)):
+    if circ.z is None:                  # cached shape: the assignment is produced on the device while the proof runs
+        t0 = time.perf_counter()
+        proof, inf, pub, _ = dev.prove_matrix(ph, rh, circ.matrices[0], circ.matrices[1], r, s)
+        proving_time = time.perf_counter() - t0
+        circ.public_inputs = pub
+        wh = None
+    else:
+        wh = dev.witness_load(circ.z)
+        t0 = time.perf_counter()
+        proof, inf = dev.prove_resident(ph, rh, wh, r, s)
+        proving_time = time.perf_counter() - t0
+    for f, h in ((dev.pk_free, ph),) + (((dev.witness_free, wh),) if wh is not None else ()) + (() if cached else ((dev.r1cs_free, rh),)):
         f(h)
     return dict(proof=proof, inf=inf, vk=vk, pk=pk, setup_time=setup_time, proving_time=proving_time, r=r, s=s)
 
