@@ -20,6 +20,7 @@
 
 #include "../../include/zkg16.h"
 #include "ec.cuh"
+#include "hostff.hpp"
 
 using namespace zk;
 
@@ -358,7 +359,11 @@ G2Prepared prepared_from_abi(const uint64_t *in, size_t n) {
 }
 G2Affine g2_neg(const G2Affine &p) { return p.is_inf() ? p : G2Affine{p.x, f_neg(p.y)}; }
 
-// ---- membership: on the curve and in the prime-order subgroup ([r] P = O) — what ark's deserialize_compressed validates
+#include "pairing_fast.inc"
+
+// ---- membership: on the curve and in the prime-order subgroup — what ark's deserialize_compressed validates.  The subgroup part
+// is the endomorphism test of pairing_fast.inc (two / one scalar multiplications by the 64-bit |z| instead of one by the 255-bit
+// r); the plain [r] P = O test remains behind it should the start-up calibration of the endomorphism constants ever fail.
 const uint32_t *r_limbs() {
     static uint32_t l[8];
     static bool init = [] { for (int i = 0; i < 8; i++) l[i] = FrP::mod(i); return true; }();
@@ -370,11 +375,15 @@ bool g1_valid(const G1Affine &p) {
     Fq c = Fq::zero();
     c.l[0] = 4;
     if (!(fp_sqr(p.y) == fp_add(fp_mul(fp_sqr(p.x), p.x), fp_to_mont(c)))) return false;
+    const pf::Endo &en = pf::endo();
+    if (en.fast_g1) return pf::g1_endo_test(pf::g1_pt(p), en.beta);
     return xyzz_mul(G1XYZZ::from_affine(p), r_limbs()).is_inf();
 }
 bool g2_valid(const G2Affine &p) {
     if (p.is_inf()) return true;
     if (!(f_sqr(p.y) == f_add(f_mul(f_sqr(p.x), p.x), twist_b()))) return false;
+    const pf::Endo &en = pf::endo();
+    if (en.fast_g2) return pf::g2_endo_test(pf::g2_pt(p), en.cx, en.cy);
     return xyzz_mul(G2XYZZ::from_affine(p), r_limbs()).is_inf();
 }
 
@@ -386,6 +395,60 @@ A load_pt(const uint64_t *l, int inf) {
     A p;
     memcpy(&p, l, sizeof p);
     return p;
+}
+
+// ---- the fast path (pairing_fast.inc) behind the entry points
+// gamma_abc[0] + sum_i z_i gamma_abc[i] -> affine (x, y) over the 64-bit-limb field; false = the point at infinity
+bool prepared_inputs(const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs, pf::Fq64 &x, pf::Fq64 &y) {
+    using pf::Fq64;
+    auto pt = [&](size_t i) {
+        const G1Affine p = load_pt<G1Affine>(gamma_abc_g1 + 12 * i, 0);
+        return p.is_inf() ? pf::pt_inf<Fq64>() : pf::g1_pt(p);
+    };
+    pf::Pt<Fq64> acc = pt(0);
+    for (size_t i = 1; i < num_instance; i++) {
+        Fr z;
+        memcpy(&z, public_inputs + 4 * (i - 1), sizeof z);
+        const Fr zc = fp_from_mont(z);
+        uint64_t k[4];
+        memcpy(k, zc.l, sizeof k);
+        if (!(k[0] | k[1] | k[2] | k[3])) continue;
+        acc = pf::pt_add(acc, pf::pt_mul(pt(i), k, 4));
+    }
+    if (acc.inf) return false;
+    const Fq64 inv = zk::h64::inv(zk::h64::mul(acc.zz, acc.zzz));
+    x = zk::h64::mul(acc.x, zk::h64::mul(inv, acc.zzz));
+    y = zk::h64::mul(acc.y, zk::h64::mul(inv, acc.zz));
+    return true;
+}
+// prod e(P_i, Q_i) == 1 with the tower arithmetic: Q_i prepared on the fly
+bool pairing_product_is_one_fast(const std::vector<MillerPair> &pairs) {
+    std::vector<pf::Prepared> prep;
+    prep.reserve(pairs.size());
+    std::vector<pf::PairIn> in;
+    for (const auto &m : pairs)
+        if (!m.p.is_inf() && !m.q.is_inf()) prep.push_back(pf::prepare(m.q));
+    size_t k = 0;
+    for (const auto &m : pairs)
+        if (!m.p.is_inf() && !m.q.is_inf()) in.push_back(pf::PairIn{pf::Fq64::from(m.p.x), pf::Fq64::from(m.p.y), &prep[k++]});
+    return pf::eq(pf::final_exp(pf::miller_loop(in)), pf::f12_one());
+}
+pf::Prepared prepared_from_abi_fast(const uint64_t *in, size_t n) {
+    pf::Prepared p;
+    p.infinity = n == 0;
+    p.ell.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        EllCoeff e;
+        memcpy(&e, in + 36 * i, sizeof e);
+        p.ell[i] = pf::Ell{pf::from_sat(e.c0), pf::from_sat(e.c1), pf::from_sat(e.c2)};
+    }
+    return p;
+}
+void prepared_to_abi_fast(const pf::Prepared &p, uint64_t *out /* 68 x 36 */) {
+    for (size_t i = 0; i < p.ell.size(); i++) {
+        const EllCoeff e{pf::to_sat(p.ell[i].c0), pf::to_sat(p.ell[i].c1), pf::to_sat(p.ell[i].c2)};
+        memcpy(out + 36 * i, &e, sizeof e);
+    }
 }
 
 }  // namespace
@@ -401,7 +464,9 @@ int zkg16_pairing_check(const uint64_t *g1, const uint8_t *g1_inf, const uint64_
             pairs[i].p = load_pt<G1Affine>(g1 + 12 * i, g1_inf ? g1_inf[i] : 0);
             pairs[i].q = load_pt<G2Affine>(g2 + 24 * i, g2_inf ? g2_inf[i] : 0);
         }
-        *ok = pairing_product_is_one(pairs, (flags & ZKG16_PAIRING_PLAIN_FINAL_EXP) != 0) ? 1 : 0;
+        // default: tower arithmetic on 64-bit limbs (pairing_fast.inc); with the flag: the flat implementation and the plain
+        // exponentiation by (q^12 - 1)/r — an independent second computation of the same verdict
+        *ok = ((flags & ZKG16_PAIRING_PLAIN_FINAL_EXP) ? pairing_product_is_one(pairs, true) : pairing_product_is_one_fast(pairs)) ? 1 : 0;
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
@@ -435,27 +500,25 @@ int zkg16_verify(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], const 
     if (!alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !gamma_abc_g1 || num_instance == 0 || (!public_inputs && num_instance > 1) || !proof ||
         !inf || !ok)
         return ZKG16_ERR_BAD_ARG;
-    G1XYZZ acc = G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1, 0));
-    for (size_t i = 1; i < num_instance; i++) {
-        Fr z;
-        memcpy(&z, public_inputs + 4 * (i - 1), sizeof z);
-        const Fr zc = fp_from_mont(z);
-        G1XYZZ t = xyzz_mul(G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1 + 12 * i, 0)), zc.l);
-        xyzz_add(acc, t);
-    }
-    const G1Affine X = xyzz_to_affine(acc);
     const G1Affine A = load_pt<G1Affine>(proof, inf[0]), C = load_pt<G1Affine>(proof + 36, inf[2]);
     const G2Affine B = load_pt<G2Affine>(proof + 12, inf[1]);
     // ark's Proof::deserialize_compressed validates curve and subgroup membership before the handler ever verifies
     // (io.rs:53-60); a pairing on arbitrary coordinates is not a verification
     if (!g1_valid(A) || !g2_valid(B) || !g1_valid(C)) { *ok = 0; return ZKG16_OK; }
     try {
+        const G1Affine alpha = load_pt<G1Affine>(alpha_g1, 0);
+        const G2Affine beta = load_pt<G2Affine>(beta_g2, 0), gamma = load_pt<G2Affine>(gamma_g2, 0), delta = load_pt<G2Affine>(delta_g2, 0);
+        // the key's own points: a caller that bypasses wire.py's decoder gets the guarantees of ark's deserialiser here too
+        if (alpha.is_inf() || beta.is_inf() || gamma.is_inf() || delta.is_inf() || !g1_valid(alpha) || !g2_valid(beta) || !g2_valid(gamma) || !g2_valid(delta))
+            return ZKG16_ERR_BAD_ARG;
+        pf::Fq64 xx, xy;
+        const bool have_x = prepared_inputs(gamma_abc_g1, num_instance, public_inputs, xx, xy);
         std::vector<MillerPair> pairs(4);
         pairs[0].p = A; pairs[0].q = B;
-        pairs[1].p = g1_neg(load_pt<G1Affine>(alpha_g1, 0)); pairs[1].q = load_pt<G2Affine>(beta_g2, 0);
-        pairs[2].p = g1_neg(X); pairs[2].q = load_pt<G2Affine>(gamma_g2, 0);
-        pairs[3].p = g1_neg(C); pairs[3].q = load_pt<G2Affine>(delta_g2, 0);
-        *ok = pairing_product_is_one(pairs, false) ? 1 : 0;
+        pairs[1].p = g1_neg(alpha); pairs[1].q = beta;
+        pairs[2].p = have_x ? g1_neg(G1Affine{xx.to(), xy.to()}) : G1Affine::inf(); pairs[2].q = gamma;
+        pairs[3].p = g1_neg(C); pairs[3].q = delta;
+        *ok = pairing_product_is_one_fast(pairs) ? 1 : 0;
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
@@ -470,12 +533,16 @@ int zkg16_pvk_prepare(const uint64_t alpha_g1[12], const uint64_t beta_g2[24], c
     if (!alpha_g1 || !beta_g2 || !gamma_g2 || !delta_g2 || !alpha_beta || !gamma_neg_coeffs || !delta_neg_coeffs || !n_coeffs) return ZKG16_ERR_BAD_ARG;
     try {
         const G1Affine a = load_pt<G1Affine>(alpha_g1, 0);
-        const G2Prepared b = g2_prepare(load_pt<G2Affine>(beta_g2, 0));
-        const G2Prepared g = g2_prepare(g2_neg(load_pt<G2Affine>(gamma_g2, 0))), d = g2_prepare(g2_neg(load_pt<G2Affine>(delta_g2, 0)));
-        if (g.ell.size() != ELL_COUNT || d.ell.size() != ELL_COUNT) return ZKG16_ERR_BAD_ARG;      // gamma / delta at infinity: not a key
-        fq12_to_abi(final_exp_fast(ark_multi_miller_loop({{a, &b}})), alpha_beta);
-        prepared_to_abi(g, gamma_neg_coeffs);
-        prepared_to_abi(d, delta_neg_coeffs);
+        const G2Affine beta = load_pt<G2Affine>(beta_g2, 0), gamma = load_pt<G2Affine>(gamma_g2, 0), delta = load_pt<G2Affine>(delta_g2, 0);
+        // not a key: points at infinity, off the curve or outside the prime-order subgroup (ark's deserialiser would have refused them)
+        if (a.is_inf() || beta.is_inf() || gamma.is_inf() || delta.is_inf() || !g1_valid(a) || !g2_valid(beta) || !g2_valid(gamma) || !g2_valid(delta))
+            return ZKG16_ERR_BAD_ARG;
+        const pf::Prepared b = pf::prepare(beta), g = pf::prepare(g2_neg(gamma)), d = pf::prepare(g2_neg(delta));
+        if (g.ell.size() != ELL_COUNT || d.ell.size() != ELL_COUNT) return ZKG16_ERR_BAD_ARG;
+        const pf::F12 ab = pf::final_exp(pf::miller_loop({pf::PairIn{pf::Fq64::from(a.x), pf::Fq64::from(a.y), &b}}));
+        fq12_to_abi(pf::to_flat(ab), alpha_beta);
+        prepared_to_abi_fast(g, gamma_neg_coeffs);
+        prepared_to_abi_fast(d, delta_neg_coeffs);
         *n_coeffs = ELL_COUNT;
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
@@ -493,21 +560,18 @@ int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_instance, con
         n_coeffs != ELL_COUNT || !proof || !inf || !ok)
         return ZKG16_ERR_BAD_ARG;
     try {
-        G1XYZZ acc = G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1, 0));
-        for (size_t i = 1; i < num_instance; i++) {
-            Fr z;
-            memcpy(&z, public_inputs + 4 * (i - 1), sizeof z);
-            const Fr zc = fp_from_mont(z);
-            G1XYZZ t = xyzz_mul(G1XYZZ::from_affine(load_pt<G1Affine>(gamma_abc_g1 + 12 * i, 0)), zc.l);
-            xyzz_add(acc, t);
-        }
-        const G1Affine X = xyzz_to_affine(acc);
         const G1Affine A = load_pt<G1Affine>(proof, inf[0]), C = load_pt<G1Affine>(proof + 36, inf[2]);
         const G2Affine B = load_pt<G2Affine>(proof + 12, inf[1]);
         if (!g1_valid(A) || !g2_valid(B) || !g1_valid(C)) { *ok = 0; return ZKG16_OK; }
-        const G2Prepared bp = g2_prepare(B), gp = prepared_from_abi(gamma_neg_coeffs, n_coeffs), dp = prepared_from_abi(delta_neg_coeffs, n_coeffs);
-        const Fq12 test = final_exp_fast(ark_multi_miller_loop({{A, &bp}, {X, &gp}, {C, &dp}}));
-        *ok = fq12_eq(test, fq12_from_abi(alpha_beta)) ? 1 : 0;
+        pf::Fq64 xx, xy;
+        const bool have_x = prepared_inputs(gamma_abc_g1, num_instance, public_inputs, xx, xy);
+        const pf::Prepared bp = pf::prepare(B), gp = prepared_from_abi_fast(gamma_neg_coeffs, n_coeffs), dp = prepared_from_abi_fast(delta_neg_coeffs, n_coeffs);
+        std::vector<pf::PairIn> in;
+        if (!A.is_inf() && !bp.infinity) in.push_back(pf::PairIn{pf::Fq64::from(A.x), pf::Fq64::from(A.y), &bp});
+        if (have_x) in.push_back(pf::PairIn{xx, xy, &gp});
+        if (!C.is_inf()) in.push_back(pf::PairIn{pf::Fq64::from(C.x), pf::Fq64::from(C.y), &dp});
+        const pf::F12 test = pf::final_exp(pf::miller_loop(in));
+        *ok = pf::eq(test, pf::from_flat(fq12_from_abi(alpha_beta))) ? 1 : 0;
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
     }
