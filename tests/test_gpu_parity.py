@@ -160,6 +160,29 @@ def test_msm_randomised_sizes_and_distributions(dev, oracle):
         assert ginf == einf and np.array_equal(got, exp), (trial, group, n, bits, c, seg)
 
 
+@pytest.mark.parametrize("n,c", [(3000, 0), (70000, 0), (70000, 9)])
+def test_msm_g2_lazy_products_vs_oracle(dev, oracle, n, c):
+    """G2 bucket accumulation with the one-reduction-per-component Fq2 products (option g2_lazy; operands parked in LDS):
+    same MSM value as the oracle and as the Karatsuba form, incl. repeated / inverse points (the doubling and cancellation cases)."""
+    rng = random.Random(n + c)
+    gen = oracle.point_mul("g2", G2_GEN_LIMBS, fr_canon(P.rand_fr(rng)))[0]
+    ks = [P.rand_fr(rng) for _ in range(64)]
+    pts, _ = oracle.fixed_base("g2", gen, fr_canon_vec(ks))
+    bases = pts[np.array([rng.randrange(64) for _ in range(n)])]
+    scalars = [rng.choice([0, 1, 2, P.R_MOD - 1, P.rand_fr(rng), P.rand_fr(rng)]) for _ in range(n)]
+    sc = fr_canon_vec(scalars)
+    want, winf = oracle.msm("g2", bases, sc)
+    dev.set_option("window_bits", c)
+    try:
+        for lazy in (1, 2):                       # 1: one reduction per component (default), 2: Karatsuba
+            dev.set_option("g2_lazy", lazy)
+            got, ginf = dev.msm("g2", bases, sc)
+            assert ginf == winf and np.array_equal(got, want), lazy
+    finally:
+        dev.set_option("g2_lazy", 0)
+        dev.set_option("window_bits", 0)
+
+
 @pytest.mark.parametrize("kind", ["ones", "bits", "same", "matmul_mix", "top_digit"])
 def test_msm_skewed_scalars(dev, oracle, kind):
     """Scalar distributions of the reference's witnesses: ~10% ones, zeros, bit vectors —
@@ -303,7 +326,7 @@ def test_prove_random_vs_oracle_and_exponent(dev, oracle):
     # every scheduling / tuning option leaves the proof bit-identical (the measured alternatives)
     for opt, vals in (("reduce_mode", (1, 2, 4, 0)), ("fixup_aux", (1, 0)), ("g1_waves", (1, 3, 4, 0)), ("window_bits_h", (9, 0)),
                       ("window_bits", (2, 3, 7, 11, 17, 0)), ("reduce_chunk", (4, 16, 0)), ("wm_concurrent", (0, -1)), ("fuse_pointwise", (0, 1)),
-                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0)), ("b_filter", (1, 2, 0))):
+                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0)), ("b_filter", (1, 2, 0)), ("g2_lazy", (2, 0))):
         for v in vals:
             dev.set_option(opt, v)
             p3, i3 = dev.prove_resident(ph, rh, wh, fr_mont(r), fr_mont(s))

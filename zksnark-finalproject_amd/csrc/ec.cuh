@@ -96,6 +96,39 @@ ZK_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bool neg) {
     acc.zzz = f_mul(acc.zzz, PPP);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same mixed addition for G2 with the eight Fq2 products in the one-reduction-per-component form (ffu.cuh: fq2u_mul_lazy).
+// Only for kernels with one wave per block (the bucket accumulation).
+__device__ __forceinline__ void xyzz_madd_lazy(XYZZ<Fq2U> &acc, const Affine<Fq2U> &q_in, bool neg) {
+    if (q_in.is_inf()) return;
+    Affine<Fq2U> q = q_in;
+    if (neg) q.y = f_neg(q.y);
+    if (acc.is_inf()) {
+        acc = XYZZ<Fq2U>{q.x, q.y, Fq2U::one(), Fq2U::one()};
+        return;
+    }
+    Fq2U U2 = fq2u_mul_lazy(q.x, acc.zz);
+    Fq2U S2 = fq2u_mul_lazy(q.y, acc.zzz);
+    Fq2U Pp = f_sub2(U2, acc.x);
+    Fq2U R = f_sub2(S2, acc.y);
+    if (f_is_zero_mod(Pp)) {
+        if (f_is_zero_mod(R)) acc = xyzz_dbl_affine(q);
+        else acc = XYZZ<Fq2U>::inf();
+        return;
+    }
+    Fq2U PP = f_sqr(Pp);
+    Fq2U PPP = fq2u_mul_lazy(Pp, PP);
+    Fq2U Q = fq2u_mul_lazy(acc.x, PP);
+    Fq2U X3 = f_sub(f_sqr(R), f_add(PPP, f_dbl(Q)));
+    acc.y = f_sub(fq2u_mul_lazy(R, f_sub2(Q, X3)), fq2u_mul_lazy(acc.y, PPP));
+    acc.x = X3;
+    acc.zz = fq2u_mul_lazy(acc.zz, PP);
+    acc.zzz = fq2u_mul_lazy(acc.zzz, PPP);
+}
+#else
+__host__ __device__ inline void xyzz_madd_lazy(XYZZ<Fq2U> &acc, const Affine<Fq2U> &q, bool neg) { xyzz_madd(acc, q, neg); }      // host pass of the kernel template only
+#endif
+
 // acc += q (EFD add-2008-s) with all exceptional cases.
 template <class F>
 ZK_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {

@@ -379,6 +379,70 @@ ZK_HD Fq2U fq2u_mul_inline(const Fq2U &a, const Fq2U &b) {
     const FqU s = fqu_mul_impl<false>(fqu_add(a.c0, a.c1), fqu_add(b.c0, b.c1));
     return Fq2U{fqu_sub<8>(v0, v1), fqu_sub<8>(s, fqu_add(v0, v1))};
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- Fq2 product with ONE reduction per component (bucket accumulation in G2, msm.hip):
+//   c0 = a0 b0 + (-a1) b1,   c1 = a0 b1 + a1 b0   — two fqu_mul2 (four half-products, two reductions: the same 1,176
+// multiply-adds as Karatsuba's three products, but two carry / quotient-digit passes instead of three, no sums of operands in
+// front and no subtractions behind: ~1,390 instead of ~1,610 instructions, components < 2q instead of < 10q).
+// fqu_mul2 takes four operands = 56 registers, the calling convention passes 32: two travel in registers, the other two are
+// parked in LDS by the caller ([operand][quad][lane] x 16 bytes: one ds_write_b128 / ds_read_b128 per four limbs, conflict-free)
+// and read back inside the callee while its first columns are already being multiplied.  Only kernels with ONE WAVE PER BLOCK may
+// call this (the slot is indexed by the lane); 16 KiB of static LDS per block.
+__shared__ uint4 zk_g2_opnd[4 * 4 * 64];
+__device__ __forceinline__ void g2_park(int op, const FqU &v) {
+    const unsigned lane = threadIdx.x & 63u;
+    zk_g2_opnd[(op * 4 + 0) * 64 + lane] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    zk_g2_opnd[(op * 4 + 1) * 64 + lane] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    zk_g2_opnd[(op * 4 + 2) * 64 + lane] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    zk_g2_opnd[(op * 4 + 3) * 64 + lane] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+__device__ __forceinline__ FqU g2_unpark(int op) {
+    const unsigned lane = threadIdx.x & 63u;
+    const uint4 q0 = zk_g2_opnd[(op * 4 + 0) * 64 + lane], q1 = zk_g2_opnd[(op * 4 + 1) * 64 + lane];
+    const uint4 q2 = zk_g2_opnd[(op * 4 + 2) * 64 + lane], q3 = zk_g2_opnd[(op * 4 + 3) * 64 + lane];
+    FqU v;
+    v.l[0] = q0.x; v.l[1] = q0.y; v.l[2] = q0.z; v.l[3] = q0.w; v.l[4] = q1.x; v.l[5] = q1.y; v.l[6] = q1.z; v.l[7] = q1.w;
+    v.l[8] = q2.x; v.l[9] = q2.y; v.l[10] = q2.z; v.l[11] = q2.w; v.l[12] = q3.x; v.l[13] = q3.y;
+    return v;
+}
+// a b + c d with c, d = parked operands pair (0: slots 0, 1; 1: slots 2, 3)
+__device__ __noinline__ __attribute__((weak)) FqURet fqu_mul2_lds_call(zk_v4u a0, zk_v4u a1, zk_v4u a2, zk_v2u a3, zk_v4u b0, zk_v4u b1, zk_v4u b2, zk_v2u b3, int pair) {
+    FqU a, b;
+    a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w; a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+    a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w; a.l[12] = a3.x; a.l[13] = a3.y;
+    b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w; b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w;
+    b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w; b.l[12] = b3.x; b.l[13] = b3.y;
+    const FqU c = g2_unpark(2 * pair), d = g2_unpark(2 * pair + 1);
+    const FqU r = fqu_mul2(a, b, c, d);
+    FqURet o;
+#pragma unroll
+    for (int i = 0; i < 14; i++) o.l[i] = r.l[i];
+    return o;
+}
+__device__ __forceinline__ FqU fqu_mul2_lds(const FqU &a, const FqU &b, int pair) {
+    zk_v4u a0 = {a.l[0], a.l[1], a.l[2], a.l[3]}, a1 = {a.l[4], a.l[5], a.l[6], a.l[7]}, a2 = {a.l[8], a.l[9], a.l[10], a.l[11]};
+    zk_v2u a3 = {a.l[12], a.l[13]};
+    zk_v4u b0 = {b.l[0], b.l[1], b.l[2], b.l[3]}, b1 = {b.l[4], b.l[5], b.l[6], b.l[7]}, b2 = {b.l[8], b.l[9], b.l[10], b.l[11]};
+    zk_v2u b3 = {b.l[12], b.l[13]};
+    const FqURet r = fqu_mul2_lds_call(a0, a1, a2, a3, b0, b1, b2, b3, pair);
+    FqU o;
+#pragma unroll
+    for (int i = 0; i < 14; i++) o.l[i] = r.l[i];
+    return o;
+}
+// a, b: components normalised, <= 127 q (everything a mixed addition multiplies: coordinates, level-64 differences, products)
+__device__ __forceinline__ Fq2U fq2u_mul_lazy(const Fq2U &a, const Fq2U &b) {
+    g2_park(0, fqu_sub<128>(FqU::zero(), a.c1));
+    g2_park(1, b.c1);
+    g2_park(2, a.c1);
+    g2_park(3, b.c0);
+    Fq2U r;
+    r.c0 = fqu_mul2_lds(a.c0, b.c0, 0);          // a0 b0 + (128 q - a1) b1
+    r.c1 = fqu_mul2_lds(a.c0, b.c1, 1);          // a0 b1 + a1 b0
+    return r;
+}
+#endif
+
 ZK_HD Fq2U f_sqr(const Fq2U &a) {
     // (c0+c1)(c0-c1) + 2 c0 c1 u ; squared values are differences of stored coordinates (components < 74q, or 84q for
     // 2*Y in a doubling) -> level-128 subtraction

@@ -178,7 +178,8 @@ struct AccArgs {
 };
 
 // G1: 2 waves per SIMD (<= 256 registers) hide the base-gather latency; G2's live state needs the whole file.
-template <class F, bool PIPE>
+// LAZY (G2 only): the mixed addition's Fq2 products with one reduction per component (ec.cuh: xyzz_madd_lazy)
+template <class F, bool PIPE, bool LAZY = false>
 __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate_kernel(AccArgs<F> a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *a.total_ptr;
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_accumulate
                 cur = gb;
             }
             const Affine<F> b = ldv(a.bases + (e >> 1));
-            xyzz_madd(acc, b, (e & 1u) != 0);
+            if constexpr (LAZY && FieldTraits<F>::g2) xyzz_madd_lazy(acc, b, (e & 1u) != 0);
+            else xyzz_madd(acc, b, (e & 1u) != 0);
             e = e_n;
             gb = g_n;
         }
@@ -969,6 +971,7 @@ static void msm_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &pla
         ScopedKernelTimer kt(ctx, FieldTraits<F>::g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (double)plan.n, ctx->stream);
         const bool pipe = (ctx->opt_acc_pipeline >> (FieldTraits<F>::g2 ? 1 : 0)) & 1;
         if (pipe) hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), dim3(grid), dim3(64), 0, ctx->stream, a);
+        else if (FieldTraits<F>::g2 && ctx->opt_g2_lazy) hipLaunchKernelGGL((msm_accumulate_kernel<F, false, true>), dim3(grid), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), dim3(grid), dim3(64), 0, ctx->stream, a);
     }
     static_assert(sizeof(AccArgs<F>) <= sizeof(slot.acc_args), "MsmSlot::acc_args too small");
