@@ -251,6 +251,16 @@ ZKG16_API int zkg16_prove_matrix(zkg16_ctx *ctx, uint64_t pk_handle, uint64_t r1
 /* Its host-only half (no ctx, no GPU): states (nullable) = 3 hashes x ceil(n^2/2) permutations x 3 Fr, the sponge state in
  * front of each permutation (after its two elements were absorbed); hashes = hash_a | hash_b | hash_c. */
 ZKG16_API int zkg16_matrix_sponge_states(size_t n, const uint64_t *a, const uint64_t *b, uint64_t *states, uint64_t hashes[12]);
+/* ---- the MatrixCircuit's R1CS of size n WITHOUT synthesising it constraint by constraint (csrc/matrix_plan.hpp): the sponge rows are
+ * copies of one template per permutation class with renamed variables, matrix_mul's rows have a closed form.  _dims / _host: host
+ * loops (the reference the device kernel is tested against; same arrays as zkg16_circuit_matrix + zkg16_circuit_export);
+ * zkg16_r1cs_matrix: the same arrays written by a kernel straight into HBM -> an r1cs handle as from zkg16_r1cs_load, with nothing
+ * but the templates (a few hundred KB) crossing PCIe instead of 3.7 GB at 128x128.  zkg16_r1cs_read copies a handle's arrays back. */
+ZKG16_API int zkg16_matrix_r1cs_dims(size_t n, size_t *num_constraints, size_t *num_witness, size_t nnz[3]);
+ZKG16_API int zkg16_matrix_r1cs_host(size_t n, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3]);
+ZKG16_API int zkg16_r1cs_matrix(zkg16_ctx *ctx, size_t n, uint64_t *r1cs_handle);
+ZKG16_API int zkg16_r1cs_read(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3],
+                    size_t *num_instance, size_t *num_constraints, size_t *num_variables, size_t nnz[3]);
 /* native Poseidon sponge hash of n Fr elements (Montgomery) — the public inputs hash_a/b/c of the matrix handler */
 ZKG16_API int zkg16_poseidon_hash(const uint64_t *elems, size_t n, uint64_t out[4]);
 

@@ -930,3 +930,67 @@ def test_prove_matrix_streamed_equals_two_step(dev, n, tables, parts):
         f(h)
     with pytest.raises(Exception):
         dev.prove_matrix(ph, rh, a, b, r, s)                     # freed handles
+
+
+# ---------------------------------------------------------------------------------------------- the MatrixCircuit's R1CS on the device
+@pytest.mark.parametrize("n", [2, 5, 9, 33, 46, 128])
+def test_r1cs_matrix_on_device_equals_host_synthesis(dev, n):
+    """zkg16_r1cs_matrix: the MatrixCircuit's three CSR matrices written by kernels from the plan (one template per Poseidon-
+    permutation class with renamed variables + matrix_mul's closed form) == the arrays of the full gadget-level synthesis on the
+    host (zkg16_circuit_matrix + zkg16_circuit_export), array for array; even / odd n and the headline size (86.6 M non-zeros)."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    ones = np.ones((n, n), dtype=np.uint64)
+    full = matrix_circuit(ones, ones)
+    rh = dev.r1cs_matrix(n)
+    got, nv = dev.r1cs_read(rh)
+    assert nv == full.num_vars and got["num_constraints"] == full.num_constraints and got["num_inputs"] == full.num_instance
+    for m in "abc":
+        for k, name in enumerate(("row_ptr", "col", "coeff")):
+            assert np.array_equal(got[m][k], full.r1cs[m][k]), (m, name)
+    del got
+    # and it is a working handle: the witness map on it equals the one on the uploaded matrices
+    if n <= 46:
+        rh2 = dev.r1cs_load(full.r1cs, full.num_vars)
+        wh = dev.witness_load(full.z)
+        h1 = dev.witness_map(rh, wh, full.domain)
+        h2 = dev.witness_map(rh2, wh, full.domain)
+        assert np.array_equal(h1, h2)
+        dev.r1cs_free(rh2)
+        dev.witness_free(wh)
+    dev.r1cs_free(rh)
+
+
+@pytest.mark.parametrize("n", [8, 46])
+def test_whole_request_without_host_synthesis(dev, n):
+    """A first request with nothing of the circuit built on the host: matrices by zkg16_r1cs_matrix, key by zkg16_setup_resident on
+    them, assignment + proof by zkg16_prove_matrix — the proof verifies against the hashes the call returns, equals the proof of the
+    host-synthesized flow for the same trapdoor, r, s, and fails for a wrong public input."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    from zksnark_finalproject_amd.device import scalar_mul, verify
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    rng_np = np.random.default_rng(9000 + n)
+    a = rng_np.integers(0, 1 << 50, size=(n, n), dtype=np.uint64)
+    b = rng_np.integers(0, 1 << 50, size=(n, n), dtype=np.uint64)
+    rng = random.Random(3 * n)
+    trap = np.stack([fr_mont(P.rand_fr(rng)) for _ in range(5)])
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    g1, g2 = scalar_mul("g1", g1_generator(), k)[0], scalar_mul("g2", g2_generator(), k)[0]
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    rh = dev.r1cs_matrix(n)
+    ph, vk = dev.setup_resident(rh, 4, trap, g1, g2)
+    proof, inf, pub, _ = dev.prove_matrix(ph, rh, a, b, r, s)
+    assert verify(vk, pub, proof, inf) is True
+    bad = pub.copy()
+    bad[1] = bad[0]
+    assert verify(vk, bad, proof, inf) is False
+    circ = matrix_circuit(a, b)                                     # the host-synthesized flow
+    rh2 = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    ph2, vk2 = dev.setup_resident(rh2, circ.num_instance, trap, g1, g2)
+    wh2 = dev.witness_load(circ.z)
+    want = dev.prove_resident(ph2, rh2, wh2, r, s)
+    assert np.array_equal(pub, circ.public_inputs)
+    assert np.array_equal(proof, want[0]) and np.array_equal(inf, want[1])
+    for key in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1"):
+        assert np.array_equal(np.asarray(vk[key]), np.asarray(vk2[key])), key
+    for f, h in ((dev.pk_free, ph), (dev.pk_free, ph2), (dev.r1cs_free, rh), (dev.r1cs_free, rh2), (dev.witness_free, wh2)):
+        f(h)

@@ -69,6 +69,10 @@ SIGNATURES = {
     "zkg16_circuit_is_satisfied": (C.c_int, [vp]),
     "zkg16_circuit_export": (C.c_int, [vp, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3), u64p]),
     "zkg16_poseidon_hash": (C.c_int, [u64p, sz, u64p]),
+    "zkg16_r1cs_matrix": (C.c_int, [ctxp, sz, C.POINTER(H)]),
+    "zkg16_r1cs_read": (C.c_int, [ctxp, H, vp, vp, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
+    "zkg16_matrix_r1cs_dims": (C.c_int, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
+    "zkg16_matrix_r1cs_host": (C.c_int, [sz, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3)]),
     "zkg16_witness_matrix": (C.c_int, [ctxp, sz, u64p, u64p, C.POINTER(H), vp, vp]),
     "zkg16_prove_matrix": (C.c_int, [ctxp, H, H, sz, u64p, u64p, u64p, u64p, u64p, u8p, vp, vp]),
     "zkg16_matrix_sponge_states": (C.c_int, [sz, u64p, u64p, vp, u64p]),

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libzkg16.so")
-SOURCES = ["api.hip", "ntt.hip", "poly.hip", "msm.hip", "sort.hip", "bucket_sort.hip", "setup.hip", "circuits.hip", "verify.hip", "witness.hip"]
-HEADERS = ["ff.cuh", "ffu.cuh", "fru.cuh", "ec.cuh", "common.hpp", "hostff.hpp", "poseidon_params.inc", "prime_circuit.inc", "final_exp.inc", os.path.join("..", "..", "include", "zkg16.h")]
+SOURCES = ["api.hip", "ntt.hip", "poly.hip", "msm.hip", "sort.hip", "bucket_sort.hip", "setup.hip", "circuits.hip", "verify.hip", "witness.hip", "matrix_r1cs.hip"]
+HEADERS = ["ff.cuh", "ffu.cuh", "fru.cuh", "ec.cuh", "common.hpp", "hostff.hpp", "matrix_plan.hpp", "pairing_fast.inc", "poseidon_h64.inc", "poseidon_params.inc", "prime_circuit.inc", "final_exp.inc", os.path.join("..", "..", "include", "zkg16.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 

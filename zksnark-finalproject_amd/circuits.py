@@ -76,6 +76,26 @@ def matrix_sponge_states(a, b):
     return states, hashes
 
 
+def matrix_r1cs_from_plan(n):
+    """The MatrixCircuit's R1CS of size n from its plan (zkg16_matrix_r1cs_dims / _host: templates + closed forms, host loops) ->
+    (r1cs dict as SynthesizedCircuit.r1cs, num_witness).  What the device kernel of zkg16_r1cs_matrix is tested against."""
+    lib = _lib.load()
+    nc, nw = C.c_size_t(), C.c_size_t()
+    nnz = (C.c_size_t * 3)()
+    rc = lib.zkg16_matrix_r1cs_dims(n, C.byref(nc), C.byref(nw), C.byref(nnz))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_matrix_r1cs_dims")
+    rp = [np.zeros(nc.value + 1, dtype=np.uint64) for _ in range(3)]
+    col = [np.zeros(max(nnz[m], 1), dtype=np.uint32) for m in range(3)]
+    cf = [np.zeros((max(nnz[m], 1), 4), dtype=np.uint64) for m in range(3)]
+    arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+    rc = lib.zkg16_matrix_r1cs_host(n, C.byref(arr(rp)), C.byref(arr(col)), C.byref(arr(cf)))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_matrix_r1cs_host")
+    return dict(a=(rp[0], col[0][:nnz[0]], cf[0][:nnz[0]]), b=(rp[1], col[1][:nnz[1]], cf[1][:nnz[1]]),
+                c=(rp[2], col[2][:nnz[2]], cf[2][:nnz[2]]), num_inputs=4, num_constraints=nc.value), nw.value
+
+
 def fibonacci_circuit(a, b, steps):
     h = C.c_void_p()
     rc = _lib.load().zkg16_circuit_fibonacci(a, b, steps, C.byref(h))

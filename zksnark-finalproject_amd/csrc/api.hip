@@ -1230,6 +1230,39 @@ int zkg16_r1cs_load(zkg16_ctx *ctx,
     ZK_API_END(ctx)
 }
 
+// The MatrixCircuit's R1CS of size n written on the device (matrix_r1cs.hip): a handle as zkg16_r1cs_load would return for the
+// arrays of zkg16_circuit_matrix + zkg16_circuit_export, without synthesising or uploading them.
+int zkg16_r1cs_matrix(zkg16_ctx *ctx, size_t n, uint64_t *r1cs_handle) {
+    if (!r1cs_handle || n < 2 || n > 1024) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    int st = ZKG16_OK;
+    std::shared_ptr<R1csDev> r = matrix_r1cs_on_device(ctx, n, &st);
+    if (!r) return st;
+    *r1cs_handle = ctx->next_handle++;
+    ctx->r1cs.put(*r1cs_handle, std::move(r));
+    ZK_API_END(ctx)
+}
+
+// The arrays behind an r1cs handle, copied back (tests compare the device-written MatrixCircuit with the host synthesis).  Each
+// pointer may be null; sizes as at load (num_constraints + 1 row pointers, nnz columns / coefficients per matrix).
+int zkg16_r1cs_read(zkg16_ctx *ctx, uint64_t r1cs_handle, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3],
+                    size_t *num_instance, size_t *num_constraints, size_t *num_variables, size_t nnz[3]) {
+    ZK_API_BEGIN(ctx)
+    auto rc_ref = ctx->r1cs.get(r1cs_handle); R1csDev *rc = rc_ref.get();
+    if (!rc) return ZKG16_ERR_BAD_HANDLE;
+    if (num_instance) *num_instance = rc->num_instance;
+    if (num_constraints) *num_constraints = rc->num_constraints;
+    if (num_variables) *num_variables = rc->num_variables;
+    for (int m = 0; m < 3; m++) {
+        if (nnz) nnz[m] = rc->nnz[m];
+        if (row_ptr && row_ptr[m]) ZK_HIP(hipMemcpyAsync(row_ptr[m], rc->rp[m].p, (rc->num_constraints + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (col && col[m] && rc->nnz[m]) ZK_HIP(hipMemcpyAsync(col[m], rc->col[m].p, rc->nnz[m] * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (coeff && coeff[m] && rc->nnz[m]) ZK_HIP(hipMemcpyAsync(coeff[m], rc->cf[m].p, rc->nnz[m] * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_API_END(ctx)
+}
+
 void zkg16_r1cs_free(zkg16_ctx *ctx, uint64_t h) {
     if (!ctx) return;
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -25,6 +25,7 @@
 
 #include "../../include/zkg16.h"
 #include "ff.cuh"
+#include "matrix_plan.hpp"
 
 using namespace zk;
 
@@ -516,7 +517,260 @@ namespace {
 size_t poseidon_hash_witnesses(size_t count) { return (count + POSEIDON_RATE - 1) / POSEIDON_RATE * 265 - 5; }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ the MatrixCircuit's R1CS as a plan
+// (matrix_plan.hpp).  The templates come out of the same gadget code the full synthesis runs, on a scratch circuit with
+// at most nine absorbed elements: permutations 0, 1, 2 (and 3, to check that a later one reuses 2's template) and, for an odd
+// element count, the last one with its single element.
+namespace {
+
+bool build_hash_plan(size_t n_elems_real, uint32_t elem_vars, MatrixPlanHash &out, std::vector<Term> *state1_last /* state[1] after the last permutation, real witness-relative ids */) {
+    const size_t E = n_elems_real <= 9 ? n_elems_real : (n_elems_real % 2 == 0 ? 8 : 9);
+    Circuit cs;
+    std::vector<Lc> elems(E);
+    for (size_t e = 0; e < E; e++) {
+        elems[e] = cs.new_witness(Fr::zero());
+        for (uint32_t k = 1; k < elem_vars; k++) elems[e] = Circuit::add(elems[e], cs.new_witness(Fr::zero()));
+    }
+    const size_t elem_wits = E * elem_vars;
+    PermTemplates tpls;
+    Lc st[3] = {cs.constant(Fr::zero()), cs.constant(Fr::zero()), cs.constant(Fr::zero())};
+    const size_t perms_s = (E + POSEIDON_RATE - 1) / POSEIDON_RATE;
+    std::vector<size_t> w0(perms_s), n_new(perms_s);
+    std::vector<int> used(perms_s, -1);
+    std::vector<std::vector<VarId>> slot_ids(perms_s);
+    for (size_t q = 0; q < perms_s; q++) {
+        for (size_t pos = 0; pos < (size_t)POSEIDON_RATE && q * POSEIDON_RATE + pos < E; pos++)
+            st[POSEIDON_CAP + pos] = Circuit::add(st[POSEIDON_CAP + pos], elems[q * POSEIDON_RATE + pos]);
+        std::vector<uint32_t> shape;
+        std::vector<Fr> coeff;
+        state_signature(st, slot_ids[q], shape, coeff);
+        w0[q] = cs.next_wit();
+        permute_gadget(cs, tpls, st);
+        n_new[q] = cs.next_wit() - w0[q];
+        for (size_t t = 0; t < tpls.list.size(); t++)
+            if (tpls.list[t].shape == shape && tpls.list[t].coeff.size() == coeff.size() &&
+                memcmp(tpls.list[t].coeff.data(), coeff.data(), coeff.size() * sizeof(Fr)) == 0) { used[q] = (int)t; break; }
+        if (used[q] < 0) return false;                  // the permutation could not be turned into a template
+    }
+    const bool odd = n_elems_real % 2 == 1;
+    // every scratch permutation from the third on (except an odd tail) must replay permutation 2's template
+    for (size_t q = 3; q < perms_s; q++)
+        if (!(odd && q + 1 == perms_s) && used[q] != used[2]) return false;
+    out.perms = (uint32_t)((n_elems_real + POSEIDON_RATE - 1) / POSEIDON_RATE);
+    out.odd_tail = odd;
+    out.elem_vars = elem_vars;
+    auto export_tpl = [&](size_t q, MatrixPlanTemplate &T) -> bool {
+        const PermTemplate &P = tpls.list[used[q]];
+        T.n_slots = P.n_slots;
+        T.n_new = P.n_new;
+        T.n_rows = (uint32_t)(P.ptr[0].size() - 1);
+        T.slots.resize(P.n_slots);
+        if (slot_ids[q].size() != P.n_slots) return false;
+        for (uint32_t k = 0; k < P.n_slots; k++) {
+            const VarId v = slot_ids[q][k];
+            if (!(v & WIT)) {
+                if (v != 0) return false;               // only the constant One among the instance variables
+                T.slots[k] = MatrixPlanSlot{0, 0, 0};
+                continue;
+            }
+            const size_t w = v & ~WIT;
+            if (w < elem_wits) {
+                const size_t e = w / elem_vars;
+                if (e < q * POSEIDON_RATE || e >= q * POSEIDON_RATE + POSEIDON_RATE) return false;
+                T.slots[k] = MatrixPlanSlot{1, (uint32_t)(e - q * POSEIDON_RATE), (uint32_t)(w % elem_vars)};
+            } else {
+                if (q == 0 || w < w0[q - 1] || w >= w0[q - 1] + n_new[q - 1]) return false;
+                T.slots[k] = MatrixPlanSlot{2, (uint32_t)(w - w0[q - 1]), 0};
+            }
+        }
+        for (int m = 0; m < 3; m++) {
+            if (P.ptr[m].size() != T.n_rows + 1) return false;
+            T.ptr[m] = P.ptr[m];
+            T.id[m].resize(P.t[m].size());
+            T.coeff[m].resize(P.t[m].size());
+            for (size_t k = 0; k < P.t[m].size(); k++) { T.id[m][k] = P.t[m][k].v; T.coeff[m][k] = P.t[m][k].c; }
+        }
+        return true;
+    };
+    for (size_t q = 0; q < perms_s && q < 3; q++) {
+        if (odd && q + 1 == perms_s && q > 0) break;     // that one is the tail class
+        if (!export_tpl(q, out.tpl[q])) return false;
+        out.has[q] = true;
+    }
+    if (odd && perms_s > 1) {
+        if (!export_tpl(perms_s - 1, out.tpl[3])) return false;
+        out.has[3] = true;
+    }
+    // classes the real circuit uses must exist
+    for (uint32_t p : {0u, 1u, 2u, out.perms - 1})
+        if (p < out.perms && !out.has[out.cls(p)]) return false;
+    // state[1] after the last permutation: the last scratch permutation's leaving state is a form over ITS OWN witnesses, at the same
+    // offsets in the real last permutation (same template class)
+    if (state1_last) {
+        state1_last->clear();
+        for (const Term &x : st[POSEIDON_CAP].t) {
+            if (!(x.v & WIT)) return false;
+            const size_t w = x.v & ~WIT;
+            if (w < w0[perms_s - 1]) return false;
+            state1_last->push_back(Term{(VarId)(w - w0[perms_s - 1]), x.c});
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace zk {
+
+bool matrix_plan_build(size_t n, MatrixPlan &P) {
+    if (n < 2 || n > 1024) return false;
+    const size_t nn = n * n, ni = 4;
+    P.n = n; P.nn = nn; P.num_instance = ni;
+    std::vector<Term> s1[3];
+    if (!build_hash_plan(nn, 1, P.hash[0], &s1[0])) return false;
+    if (!build_hash_plan(nn, 1, P.hash[1], &s1[1])) return false;
+    if (!build_hash_plan(nn, (uint32_t)(n + 1), P.hash[2], &s1[2])) return false;
+    // witnesses: a | b | gadget a | gadget b | n^2 zeros | per (i, j): seed + n products | gadget c
+    uint64_t hw[3];
+    for (int h = 0; h < 3; h++) {
+        uint64_t rows, nz[3];
+        (void)rows; (void)nz;
+        hw[h] = 0;
+        for (uint32_t p = 0; p < P.hash[h].perms; p++) hw[h] += P.hash[h].tpl[P.hash[h].cls(p)].n_new;
+    }
+    P.col_a0 = ni;
+    P.col_b0 = ni + nn;
+    P.hash[0].elem_col0 = P.col_a0;
+    P.hash[1].elem_col0 = P.col_b0;
+    P.hash[0].wit_col0 = ni + 2 * nn;
+    P.hash[1].wit_col0 = P.hash[0].wit_col0 + hw[0];
+    const uint64_t mm_w0 = P.hash[1].wit_col0 + hw[1];           // the n^2 pre-allocated zeros
+    P.col_prod0 = mm_w0 + nn;                                    // block of (0, 0): [seed, n products]
+    P.hash[2].elem_col0 = P.col_prod0;
+    P.hash[2].wit_col0 = P.col_prod0 + (uint64_t)nn * (n + 1);
+    P.num_witness = (size_t)(P.hash[2].wit_col0 + hw[2] - ni);
+    // rows and non-zeros: hash a | hash b | eq a, eq b | matrix_mul | hash c | eq c
+    uint64_t row = 0, nz[3] = {0, 0, 0};
+    auto place_hash = [&](int h) {
+        P.hash[h].row0 = row;
+        for (int m = 0; m < 3; m++) P.hash[h].nnz0[m] = nz[m];
+        uint64_t r, k[3];
+        matrix_plan_prefix(P.hash[h], P.hash[h].perms, r, k);
+        row += r;
+        for (int m = 0; m < 3; m++) nz[m] += k[m];
+    };
+    const Fr one = Fr::one(), minus_one = fp_neg(Fr::one());
+    auto place_eq = [&](int which) {
+        // enforce_equal(hash, input): (state[1] - input) * 1 = 0, the instance variable first (columns are sorted)
+        const MatrixPlanHash &H = P.hash[which];
+        uint64_t last_w0 = H.wit_col0;
+        for (uint32_t p = 0; p + 1 < H.perms; p++) last_w0 += H.tpl[H.cls(p)].n_new;
+        MatrixPlanRow &A = P.eq[which][0], &B = P.eq[which][1], &C = P.eq[which][2];
+        A.col.clear(); A.coeff.clear(); B.col.clear(); B.coeff.clear(); C.col.clear(); C.coeff.clear();
+        A.col.push_back((uint32_t)(which + 1));          // hash_a, hash_b, hash_c are instance variables 1, 2, 3
+        A.coeff.push_back(minus_one);
+        for (const Term &x : s1[which]) { A.col.push_back((uint32_t)(last_w0 + x.v)); A.coeff.push_back(x.c); }
+        B.col.push_back(0);
+        B.coeff.push_back(one);
+        P.eq_row[which] = row;
+        for (int m = 0; m < 3; m++) { P.eq_nnz0[which][m] = nz[m]; nz[m] += P.eq[which][m].col.size(); }
+        row += 1;
+    };
+    place_hash(0);
+    place_hash(1);
+    place_eq(0);
+    place_eq(1);
+    P.mm_row0 = row;
+    for (int m = 0; m < 3; m++) { P.mm_nnz0[m] = nz[m]; nz[m] += 2 * (uint64_t)nn * n; }
+    row += 2 * (uint64_t)nn * n;
+    place_hash(2);
+    place_eq(2);
+    P.num_constraints = (size_t)row;
+    for (int m = 0; m < 3; m++) P.nnz[m] = nz[m];
+    return P.num_instance + P.num_witness < ((uint64_t)1 << 32);
+}
+
+// the plan written out by plain loops: the reference the device kernel (matrix_r1cs.hip) is tested against, itself tested against
+// the full synthesis (zkg16_circuit_matrix + zkg16_circuit_export)
+void matrix_plan_instantiate_host(const MatrixPlan &P, uint64_t *const rp[3], uint32_t *const col[3], Fr *const cf[3]) {
+    const Fr one = Fr::one();
+    for (int m = 0; m < 3; m++) rp[m][0] = 0;
+    for (int h = 0; h < 3; h++) {
+        const MatrixPlanHash &H = P.hash[h];
+        uint64_t w0_prev = 0, w0 = H.wit_col0;
+        for (uint32_t p = 0; p < H.perms; p++) {
+            const MatrixPlanTemplate &T = H.tpl[H.cls(p)];
+            uint64_t r0, k0[3];
+            matrix_plan_prefix(H, p, r0, k0);
+            auto real = [&](uint32_t id) -> uint32_t {
+                if (id >= T.n_slots) return (uint32_t)(w0 + (id - T.n_slots));
+                const MatrixPlanSlot &sl = T.slots[id];
+                if (sl.kind == 0) return 0;
+                if (sl.kind == 1) return (uint32_t)(H.elem_col0 + ((uint64_t)POSEIDON_RATE * p + sl.a) * H.elem_vars + sl.b);
+                return (uint32_t)(w0_prev + sl.a);
+            };
+            for (int m = 0; m < 3; m++) {
+                const uint64_t kb = H.nnz0[m] + k0[m];
+                for (uint32_t r = 0; r < T.n_rows; r++) rp[m][H.row0 + r0 + r + 1] = kb + T.ptr[m][r + 1];
+                for (size_t k = 0; k < T.id[m].size(); k++) { col[m][kb + k] = real(T.id[m][k]); cf[m][kb + k] = T.coeff[m][k]; }
+            }
+            w0_prev = w0;
+            w0 += T.n_new;
+        }
+    }
+    for (int w = 0; w < 3; w++)
+        for (int m = 0; m < 3; m++) {
+            const MatrixPlanRow &R = P.eq[w][m];
+            for (size_t k = 0; k < R.col.size(); k++) { col[m][P.eq_nnz0[w][m] + k] = R.col[k]; cf[m][P.eq_nnz0[w][m] + k] = R.coeff[k]; }
+            rp[m][P.eq_row[w] + 1] = P.eq_nnz0[w][m] + R.col.size();
+        }
+    const size_t n = P.n;
+    for (uint64_t t = 0; t < 2 * (uint64_t)P.nn * n; t++) {
+        const uint64_t pr = t >> 1, cell = pr / n, k = pr % n, i = cell / n, j = cell % n;
+        const uint32_t c[3] = {(uint32_t)(P.col_a0 + i * n + k), (uint32_t)(P.col_b0 + k * n + j), (uint32_t)(P.col_prod0 + cell * (n + 1) + 1 + k)};
+        for (int m = 0; m < 3; m++) {
+            col[m][P.mm_nnz0[m] + t] = c[m];
+            cf[m][P.mm_nnz0[m] + t] = one;
+            rp[m][P.mm_row0 + t + 1] = P.mm_nnz0[m] + t + 1;
+        }
+    }
+}
+
+}  // namespace zk
+
 extern "C" {
+
+// The MatrixCircuit's R1CS of size n from its plan (host loops): dims, then the CSR arrays as zkg16_circuit_export lays them out.
+int zkg16_matrix_r1cs_dims(size_t n, size_t *num_constraints, size_t *num_witness, size_t nnz[3]) {
+    try {
+        MatrixPlan P;
+        if (!matrix_plan_build(n, P)) return ZKG16_ERR_UNSUPPORTED;
+        if (num_constraints) *num_constraints = P.num_constraints;
+        if (num_witness) *num_witness = P.num_witness;
+        if (nnz) for (int m = 0; m < 3; m++) nnz[m] = (size_t)P.nnz[m];
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    } catch (const std::exception &) {
+        g_terms = true;
+        return ZKG16_ERR_UNSUPPORTED;
+    }
+    return ZKG16_OK;
+}
+int zkg16_matrix_r1cs_host(size_t n, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3]) {
+    if (!row_ptr || !col || !coeff) return ZKG16_ERR_BAD_ARG;
+    try {
+        MatrixPlan P;
+        if (!matrix_plan_build(n, P)) return ZKG16_ERR_UNSUPPORTED;
+        Fr *cf[3] = {reinterpret_cast<Fr *>(coeff[0]), reinterpret_cast<Fr *>(coeff[1]), reinterpret_cast<Fr *>(coeff[2])};
+        matrix_plan_instantiate_host(P, row_ptr, col, cf);
+    } catch (const std::bad_alloc &) {
+        return ZKG16_ERR_OOM;
+    } catch (const std::exception &) {
+        g_terms = true;
+        return ZKG16_ERR_UNSUPPORTED;
+    }
+    return ZKG16_OK;
+}
 
 // FibonacciCircuit { a, b, num_of_steps, result } with result computed in Fr (the reference's u128 helper overflows
 // above 186 rounds: SURVEY.md F8).

@@ -369,6 +369,14 @@ G2XYZZ msm_g2_exec(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const 
 void convert_g1_bases(zkg16_ctx *ctx, const G1Affine *in, G1AffineU *out, size_t n);
 void convert_g2_bases(zkg16_ctx *ctx, const G2Affine *in, G2AffineU *out, size_t n);
 
+// circuits.hip: the MatrixCircuit's R1CS of size n as a plan (matrix_plan.hpp), and its reference instantiation on the host
+struct MatrixPlan;
+bool matrix_plan_build(size_t n, MatrixPlan &plan);
+void matrix_plan_instantiate_host(const MatrixPlan &plan, uint64_t *const rp[3], uint32_t *const col[3], Fr *const cf[3]);
+
+// matrix_r1cs.hip: that R1CS written by kernels into a new R1csDev (status: a zkg16_status when the result is null)
+std::shared_ptr<R1csDev> matrix_r1cs_on_device(zkg16_ctx *ctx, size_t n, int *status);
+
 // witness.hip: the MatrixCircuit's assignment arriving on the device in parts (zkg16_witness_matrix: all at once;
 // zkg16_prove_matrix: while the proof is already running).  slices_wanted gadget slices -> parts = slices + 1.
 struct MatrixWitnessStream;

@@ -129,6 +129,26 @@ class Device:
         self._check(self.lib.zkg16_r1cs_load(self.ctx, *args, r1cs["num_inputs"], r1cs["num_constraints"], num_variables, C.byref(handle)))
         return handle.value
 
+    def r1cs_matrix(self, n):
+        """The MatrixCircuit's R1CS of size n written on the device (zkg16_r1cs_matrix) -> r1cs handle."""
+        handle = C.c_uint64()
+        self._check(self.lib.zkg16_r1cs_matrix(self.ctx, n, C.byref(handle)))
+        return handle.value
+
+    def r1cs_read(self, h):
+        """-> the r1cs dict (as SynthesizedCircuit.r1cs) + num_variables behind a handle (zkg16_r1cs_read)."""
+        ni, nc, nv = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        nnz = (C.c_size_t * 3)()
+        self._check(self.lib.zkg16_r1cs_read(self.ctx, h, None, None, None, C.byref(ni), C.byref(nc), C.byref(nv), C.byref(nnz)))
+        rp = [np.zeros(nc.value + 1, dtype=np.uint64) for _ in range(3)]
+        col = [np.zeros(max(nnz[m], 1), dtype=np.uint32) for m in range(3)]
+        cf = [np.zeros((max(nnz[m], 1), 4), dtype=np.uint64) for m in range(3)]
+        arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+        a, b, c = arr(rp), arr(col), arr(cf)
+        self._check(self.lib.zkg16_r1cs_read(self.ctx, h, C.addressof(a), C.addressof(b), C.addressof(c), None, None, None, None))
+        return dict(a=(rp[0], col[0][:nnz[0]], cf[0][:nnz[0]]), b=(rp[1], col[1][:nnz[1]], cf[1][:nnz[1]]),
+                    c=(rp[2], col[2][:nnz[2]], cf[2][:nnz[2]]), num_inputs=ni.value, num_constraints=nc.value), nv.value
+
     def r1cs_free(self, h):
         self.lib.zkg16_r1cs_free(self.ctx, h)
 

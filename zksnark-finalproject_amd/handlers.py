@@ -31,6 +31,22 @@ class _CachedShape:
         self.num_instance, self.num_witness, self.num_vars = circ.num_instance, circ.num_witness, circ.num_vars
         self.num_constraints, self.domain = circ.num_constraints, circ.domain
 
+    @classmethod
+    def on_device(cls, dev, n):
+        """The shape with its matrices written ON THE DEVICE (zkg16_r1cs_matrix): nothing of the circuit is synthesized on the host."""
+        import ctypes as C
+        from . import _lib
+        nc, nw = C.c_size_t(), C.c_size_t()
+        rc = _lib.load().zkg16_matrix_r1cs_dims(n, C.byref(nc), C.byref(nw), None)
+        if rc:
+            raise _lib.Zkg16Error(rc, "zkg16_matrix_r1cs_dims")
+        self = cls.__new__(cls)
+        self.rh = dev.r1cs_matrix(n)
+        self.num_instance, self.num_witness, self.num_vars = 4, nw.value, 4 + nw.value
+        self.num_constraints = nc.value
+        self.domain = 1 << max(nc.value + 4 - 1, 0).bit_length()
+        return self
+
     def instantiate(self, a, b):
         """The request's circuit without a host assignment: z is built on the device inside the proof (zkg16_prove_matrix)."""
         inst = _CachedShape.__new__(_CachedShape)
@@ -86,8 +102,7 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
     elif size in shapes:
         circ = shapes[size].instantiate(a, b)
     else:
-        full = matrix_circuit(a, b)
-        shapes[size] = _CachedShape(full, dev.r1cs_load(full.r1cs, full.num_vars))
+        shapes[size] = _CachedShape.on_device(dev, size)           # first request of this size: matrices written by kernels
         circ = shapes[size].instantiate(a, b)
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     ha, hb, hc = circ.public_inputs
