@@ -140,3 +140,77 @@ extern "C" void ht_fru_op(int op, const uint32_t *a, const uint32_t *b, uint32_t
     }
     st(o, fru_mul_to_sat(r, fru_one_sat()));
 }
+
+// ---------------------------------------------------------------------------------------------- host-only 64-bit-limb fields (hostff.hpp)
+// and the verifier's tower arithmetic (pairing_fast.inc), as verify.hip includes it
+#include "hostff.hpp"
+#include <vector>
+namespace {
+#include "final_exp.inc"
+const uint64_t Z_ABS = 0xd201000000010000ULL;
+struct Fq12 { Fq2 c[6]; };
+#include "pairing_fast.inc"
+template <class P> void h64_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o) {
+    using F = zk::h64::F<P>;
+    F x, y, r;
+    memcpy(x.l, a, sizeof x.l);
+    memcpy(y.l, b, sizeof y.l);
+    switch (op) {
+        case 0: r = zk::h64::add(x, y); break;
+        case 1: r = zk::h64::sub(x, y); break;
+        case 2: r = zk::h64::mul(x, y); break;
+        case 3: r = zk::h64::sqr(x); break;
+        case 4: r = zk::h64::inv(x); break;
+        case 5: r = zk::h64::neg(x); break;
+        case 6: r = zk::h64::to_mont(x); break;
+        case 7: r = zk::h64::from_mont(x); break;
+        default: r = x;
+    }
+    memcpy(o, r.l, sizeof r.l);
+}
+// ABI order of an Fq12 (ark's tower order) = the field order of pf::F12
+pf::F12 f12_ld(const uint64_t *p) { pf::F12 a; memcpy(&a, p, sizeof a); return a; }
+void f12_st(uint64_t *p, const pf::F12 &a) { memcpy(p, &a, sizeof a); }
+}  // namespace
+extern "C" {
+void ht_h64_fr_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o) { h64_op<FrP>(op, a, b, o); }
+void ht_h64_fq_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o) { h64_op<FqP>(op, a, b, o); }
+// op 0 mul, 1 sqr, 2 inv, 3 mul_by_014 (b: l0 = b[0..12), l1 = b[12..24), l4 = b[24..36)), 4 frobenius (times = b[0]), 5 conj
+void ht_f12_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o) {
+    static_assert(sizeof(pf::F12) == 72 * 8, "layout");
+    const pf::F12 x = f12_ld(a);
+    pf::F12 r;
+    switch (op) {
+        case 0: r = pf::mul(x, f12_ld(b)); break;
+        case 1: r = pf::sqr(x); break;
+        case 2: r = pf::inv(x); break;
+        case 3: { pf::F2 l[3]; memcpy(l, b, sizeof l); r = pf::mul_by_014(x, l[0], l[1], l[2]); break; }
+        case 4: r = pf::frob(x, (int)b[0]); break;
+        default: r = pf::conj(x);
+    }
+    f12_st(o, r);
+}
+// the shortcuts that only hold in the cyclotomic subgroup, against the generic arithmetic, on g = f^((q^6 - 1)(q^2 + 1)):
+// bit 0: cyclotomic_sqr(g) == sqr(g), bit 1: conj(g) == inv(g), bit 2: pow_z(g) == generic g^|z| conjugated, bit 3: final_exp(f) is in
+// the subgroup of order r (its r-th power is one is not checked here: its cube-free equality with the plain exponent is, in
+// tests/test_verify_pairing.py); bit 4: the endomorphism constants were calibrated (fast subgroup tests in use)
+int ht_f12_cyclotomic_checks(const uint64_t *a) {
+    const pf::F12 f = f12_ld(a);
+    const pf::F12 f1 = pf::mul(pf::conj(f), pf::inv(f));
+    const pf::F12 g = pf::mul(pf::frob(f1, 2), f1);
+    int ok = 0;
+    if (pf::eq(pf::cyclotomic_sqr(g), pf::sqr(g))) ok |= 1;
+    if (pf::eq(pf::mul(pf::conj(g), g), pf::f12_one())) ok |= 2;
+    pf::F12 acc = g;
+    for (int i = 62; i >= 0; i--) {
+        acc = pf::sqr(acc);
+        if ((Z_ABS >> i) & 1) acc = pf::mul(acc, g);
+    }
+    if (pf::eq(pf::pow_z(g), pf::conj(acc))) ok |= 4;
+    const pf::F12 e = pf::final_exp(f);
+    if (pf::eq(pf::mul(pf::conj(e), e), pf::f12_one())) ok |= 8;
+    const pf::Endo &en = pf::endo();
+    if (en.fast_g1 && en.fast_g2) ok |= 16;
+    return ok;
+}
+}

@@ -232,3 +232,80 @@ def test_fru_ops_vs_python(shim):
         a, b = vals[i], vals[i + 1]
         for op, f in ops:
             assert P.fr_from_mont(unlimbs(call_field(shim, "ht_fru_op", op, fr_mont(a), fr_mont(b)))) == f(a, b) % r, (op, a, b)
+
+
+# ---------------------------------------------------------------------------------------------- host-only 64-bit-limb arithmetic
+def _call64(shim, name, op, a, b):
+    a64, b64 = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    o = np.zeros_like(a64)
+    getattr(shim, name)(op, a64.ctypes.data_as(C.c_void_p), b64.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
+    return o
+
+
+@pytest.mark.parametrize("field", ["fr", "fq"])
+def test_h64_fields_vs_python(shim, field):
+    """csrc/hostff.hpp (the host chains of the device witness generator and the verifier run on it): add / sub / mul / sqr / inv /
+    neg / to_mont / from_mont against Python big ints, on the golden vectors, random values and the edges 0, 1, p - 1."""
+    nl, mod, to_m, from_m = (4, P.R_MOD, P.fr_to_mont, P.fr_from_mont) if field == "fr" else (6, P.Q_MOD, P.fq_to_mont, P.fq_from_mont)
+    name = "ht_h64_%s_op" % field
+    rng = random.Random(64)
+    vals = [(H(v["a"]), H(v["b"])) for v in load("field_kat.json")[field]]
+    vals += [(rng.randrange(mod), rng.randrange(mod)) for _ in range(200)]
+    vals += [(0, 0), (0, 1), (1, mod - 1), (mod - 1, mod - 1), (mod - 1, 1), (2, (mod + 1) // 2)]
+    for x, y in vals:
+        a, b = limbs(to_m(x), nl), limbs(to_m(y), nl)
+        got = lambda op: from_m(unlimbs(_call64(shim, name, op, a, b)))
+        assert got(0) == (x + y) % mod and got(1) == (x - y) % mod and got(2) == x * y % mod
+        assert got(3) == x * x % mod and got(5) == (-x) % mod
+        if x:
+            assert got(4) == pow(x, -1, mod)
+        assert unlimbs(_call64(shim, name, 6, limbs(x, nl), b)) == to_m(x)
+        assert unlimbs(_call64(shim, name, 7, a, b)) == x
+
+
+def test_verifier_tower_arithmetic_vs_python(shim):
+    """csrc/pairing_fast.inc: Fq12 as Fq6[w]/(w^2 - v) over Fq2[v]/(v^3 - xi) on 64-bit limbs — product, square, inverse, the sparse
+    line product mul_by_014, Frobenius and conjugation against the flat pure-Python Fq12 (tests/golden/pyref_pairing.py); the
+    cyclotomic-subgroup shortcuts (Granger-Scott squaring, conjugate = inverse, the |z| ladder) against the generic arithmetic;
+    and the start-up calibration of the endomorphism constants must have succeeded (fast subgroup tests in use)."""
+    import pyref_pairing as PP
+    rng = random.Random(12)
+    tower = [0, 2, 4, 1, 3, 5]                 # ABI slot k holds the coefficient of w^tower[k]
+
+    def rand12():
+        return PP.Fq12([P.Fq2(rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD)) for _ in range(6)])
+
+    def to_abi(f):
+        out = []
+        for k in range(6):
+            c = f.c[tower[k]]
+            out += list(limbs(P.fq_to_mont(c.c0), 6)) + list(limbs(P.fq_to_mont(c.c1), 6))
+        return np.array(out, dtype=np.uint64)
+
+    def from_abi(a):
+        c = [None] * 6
+        for k in range(6):
+            c[tower[k]] = P.Fq2(P.fq_from_mont(unlimbs(a[12 * k:12 * k + 6])), P.fq_from_mont(unlimbs(a[12 * k + 6:12 * k + 12])))
+        return PP.Fq12(c)
+
+    def call(op, a, b):
+        o = np.zeros(72, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        shim.ht_f12_op(op, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
+        return from_abi(o)
+    for _ in range(4):
+        x, y = rand12(), rand12()
+        ax, ay = to_abi(x), to_abi(y)
+        assert call(0, ax, ay) == x * y
+        assert call(1, ax, ay) == x * x
+        assert call(2, ax, ay) * x == PP.Fq12.one()
+        # sparse line l0 + l1 w^2 + l4 w^3
+        l = [P.Fq2(rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD)) for _ in range(3)]
+        sparse = PP.Fq12([l[0], P.Fq2(0, 0), l[1], l[2], P.Fq2(0, 0), P.Fq2(0, 0)])
+        lb = np.array(sum([list(limbs(P.fq_to_mont(c.c0), 6)) + list(limbs(P.fq_to_mont(c.c1), 6)) for c in l], []) + [0] * 36, dtype=np.uint64)
+        assert call(3, ax, lb) == x * sparse
+        for times in (1, 2):
+            assert call(4, ax, np.array([times] + [0] * 71, dtype=np.uint64)) == x.pow(P.Q_MOD ** times)
+        assert call(5, ax, ay) == x.pow(P.Q_MOD ** 6)
+        shim.ht_f12_cyclotomic_checks.restype = C.c_int
+        assert shim.ht_f12_cyclotomic_checks(ax.ctypes.data_as(C.c_void_p)) == 31
