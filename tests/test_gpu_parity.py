@@ -556,6 +556,31 @@ def test_error_paths(dev):
         dev.lib.zkg16_ntt.argtypes  # noqa
         dev._check(dev.lib.zkg16_ntt(dev.ctx, np.zeros((1, 4), np.uint64), 40, 0, 0))
     assert e.value.status == 2       # domain too large
+    # the matrix request's entry points: sizes that are not a MatrixCircuit, handles of another size, unknown handles
+    two = np.ones((2, 2), dtype=np.uint64)
+    one = np.ones((1, 1), dtype=np.uint64)
+    for call in (lambda: dev.witness_matrix(one, one), lambda: dev.r1cs_matrix(1), lambda: dev.r1cs_matrix(5000)):
+        with pytest.raises(Zkg16Error) as e:
+            call()
+        assert e.value.status == 1
+    rh3 = dev.r1cs_matrix(3)
+    from zksnark_finalproject_amd.device import scalar_mul
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    trap = np.stack([fr_mont(k + 2) for k in range(5)])
+    ph3, _ = dev.setup_resident(rh3, 4, trap, g1_generator(), g2_generator())
+    with pytest.raises(Zkg16Error) as e:
+        dev.prove_matrix(ph3, rh3, two, two, fr_mont(1), fr_mont(2))      # a 2x2 request on the 3x3 circuit's handles
+    assert e.value.status == 1
+    with pytest.raises(Zkg16Error) as e:
+        dev.prove_matrix(ph3, 999999, np.ones((3, 3), dtype=np.uint64), np.ones((3, 3), dtype=np.uint64), fr_mont(1), fr_mont(2))
+    assert e.value.status == 6
+    ok = dev.prove_matrix(ph3, rh3, np.ones((3, 3), dtype=np.uint64), np.ones((3, 3), dtype=np.uint64), fr_mont(1), fr_mont(2))
+    assert ok[0].any()                                                    # and the ctx still proves after the refusals
+    dev.pk_free(ph3)
+    dev.r1cs_free(rh3)
+    for name, v in (("lanes", 0), ("lanes", 9), ("matrix_parts", 9), ("g2_lazy", 3)):
+        with pytest.raises(Zkg16Error):
+            dev.set_option(name, v)
 
 
 @pytest.mark.parametrize("kind", ["fib0", "fib10", "fib186", "fib1000", "matrix3", "matrix8", "matrix32", "prime"])
@@ -738,6 +763,7 @@ def test_concurrent_callers_on_one_ctx(dev, oracle):
     zm = fr_mont_vec(z)
     ph, rh, wh = dev.pk_load(pk, ni), dev.r1cs_load(r1cs, nv), dev.witness_load(zm)
     jobs = [(fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))) for _ in range(12)]
+    oracle.set_threads(min(os.cpu_count() or 1, 16))
     want = [oracle.prove(pk, r, s, r1cs, zm) for r, s in jobs]
     out = [None] * len(jobs)
 
@@ -994,3 +1020,39 @@ def test_whole_request_without_host_synthesis(dev, n):
         assert np.array_equal(np.asarray(vk[key]), np.asarray(vk2[key])), key
     for f, h in ((dev.pk_free, ph), (dev.pk_free, ph2), (dev.r1cs_free, rh), (dev.r1cs_free, rh2), (dev.witness_free, wh2)):
         f(h)
+
+
+def test_two_streamed_requests_at_once(dev):
+    """Two callers, each a whole matrix request (zkg16_prove_matrix) on the same resident key and device-written matrices, different
+    inputs: each gets the proof the two-step path gives for its inputs, and both verify."""
+    import threading
+    from zksnark_finalproject_amd.device import verify
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    n = 40
+    rng_np = np.random.default_rng(40)
+    inputs = [(rng_np.integers(0, 1 << 60, size=(n, n), dtype=np.uint64), rng_np.integers(0, 1 << 60, size=(n, n), dtype=np.uint64)) for _ in range(4)]
+    trap = np.stack([fr_mont(1000 + k) for k in range(5)])
+    rh = dev.r1cs_matrix(n)
+    ph, vk = dev.setup_resident(rh, 4, trap, g1_generator(), g2_generator())
+    r, s = fr_mont(77), fr_mont(99)
+    want = []
+    for a, b in inputs:
+        wh, pub, _ = dev.witness_matrix(a, b)
+        want.append((dev.prove_resident(ph, rh, wh, r, s), pub))
+        dev.witness_free(wh)
+    out = [None] * len(inputs)
+
+    def work(i):
+        out[i] = dev.prove_matrix(ph, rh, inputs[i][0], inputs[i][1], r, s)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(inputs)):
+        proof, inf, pub, _ = out[i]
+        assert np.array_equal(pub, want[i][1]) and np.array_equal(proof, want[i][0][0]) and np.array_equal(inf, want[i][0][1]), i
+        assert verify(vk, pub, proof, inf) is True
+    assert {l for l, _, _ in dev.lane_log(len(inputs))} == {0, 1}
+    dev.pk_free(ph)
+    dev.r1cs_free(rh)
