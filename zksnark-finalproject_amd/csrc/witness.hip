@@ -138,6 +138,7 @@ struct MatrixChains {
     }
 };
 
+#ifndef ZKG16_HOST_ONLY        // (tests/test_host_sanitize.py compiles the host chains alone, without kernels, under ASan)
 // ------------------------------------------------------------------------------------------------ device
 struct PoseidonDev { Fr mds[3][3], ark[P_ROUNDS][3]; };
 
@@ -255,8 +256,10 @@ __global__ void __launch_bounds__(256) wit_part_of_kernel(PartArgs g) {
     g.part_of[i] = (uint8_t)part;
 }
 
+#endif  // ZKG16_HOST_ONLY
 }  // namespace
 
+#ifndef ZKG16_HOST_ONLY
 namespace zk {
 
 struct MatrixWitnessLayout {
@@ -385,6 +388,7 @@ void matrix_stream_produce(MatrixWitnessStream *ms, zkg16_ctx *ctx, int k) {
 }
 
 }  // namespace zk
+#endif  // ZKG16_HOST_ONLY
 
 extern "C" {
 
@@ -406,6 +410,7 @@ int zkg16_matrix_sponge_states(size_t n, const uint64_t *a, const uint64_t *b, u
     return ZKG16_OK;
 }
 
+#ifndef ZKG16_HOST_ONLY
 // The MatrixCircuit's full assignment for (a, b), built on the device: a witness handle as zkg16_witness_load would return for
 // zkg16_circuit_matrix_witness's output.  public_inputs (nullable): hash_a, hash_b, hash_c (Montgomery), the handler's
 // public inputs.  timings_ms (nullable, 3): host chains, upload + kernels (device time), whole call.
@@ -471,5 +476,6 @@ int zkg16_witness_matrix(zkg16_ctx *ctx, size_t n, const uint64_t *a, const uint
     }
     return ZKG16_OK;
 }
+#endif  // ZKG16_HOST_ONLY
 
 }  // extern "C"
