@@ -518,7 +518,7 @@ def test_prime_handler_round_trip(dev):
     """prove_prime / verify_prime mirrors (backend/prime_snark.rs:49-146, 165-206): search, PrimeCircuit, device setup, device proof,
     pairing verification through the wire format with the public inputs recovered by re-synthesis; a wrong j does not verify."""
     from zksnark_finalproject_amd import handlers
-    res = handlers.prove_prime(dev, 5, 32)
+    res = handlers.prove_prime(dev, 5, 32, check_satisfied=True)
     assert res["found_prime"] and res["satisfied"] is True and int(res["prime_num"]) > 1
     assert handlers.verify_prime(res["vk"], 5, res["j"], res["proof"])["valid"] is True
     other = res["j"] + 1

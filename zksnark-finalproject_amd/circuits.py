@@ -11,14 +11,14 @@ from ._lib import Zkg16Error
 class SynthesizedCircuit:
     """num_instance (incl. the constant 1), num_witness, num_constraints, r1cs (dict of CSR triples), z (Montgomery)."""
 
-    def __init__(self, handle, check_satisfied=False):
+    def __init__(self, handle, check_satisfied=None):
         lib = _lib.load()
         ni, nw, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
         nnz = (C.c_size_t * 3)()
         lib.zkg16_circuit_dims(handle, C.byref(ni), C.byref(nw), C.byref(nc), C.byref(nnz))
         self.num_instance, self.num_witness, self.num_constraints = ni.value, nw.value, nc.value
         self.num_vars = ni.value + nw.value
-        self.satisfied = bool(lib.zkg16_circuit_is_satisfied(handle)) if (nc.value <= 200000 or check_satisfied) else None
+        self.satisfied = bool(lib.zkg16_circuit_is_satisfied(handle)) if ((nc.value <= 200000 and check_satisfied is not False) or check_satisfied) else None
         rp = [np.zeros(nc.value + 1, dtype=np.uint64) for _ in range(3)]
         col = [np.zeros(max(nnz[m], 1), dtype=np.uint32) for m in range(3)]
         cf = [np.zeros((max(nnz[m], 1), 4), dtype=np.uint64) for m in range(3)]
@@ -126,9 +126,11 @@ def prime_candidate(x, j):
     return dict(digest=bytes(digest), n=n.value, bases=[int(b) for b in bases], r_bytes=bytes(rb), is_prime=bool(isp.value))
 
 
-def prime_circuit(x, i_max_or_j, search=True):
+def prime_circuit(x, i_max_or_j, search=True, check_satisfied=True):
     """The reference's PrimeCircuit (C++ mirror).  search=True: as prove_prime — find the first prime candidate j <= i_max and
-    build its circuit (raises if none); search=False: the circuit of candidate j itself, as verify_prime rebuilds it."""
+    build its circuit (raises if none); search=False: the circuit of candidate j itself, as verify_prime rebuilds it.
+    check_satisfied: evaluate all 338 k constraints on the assignment (a test convenience — neither `Groth16::prove` nor the
+    reference's handlers do it; it costs about as much as the synthesis itself, so timed paths pass False)."""
     j = i_max_or_j
     if search:
         res = prime_search(x, i_max_or_j)
@@ -139,7 +141,7 @@ def prime_circuit(x, i_max_or_j, search=True):
     rc = _lib.load().zkg16_circuit_prime(x, j, C.byref(h))
     if rc:
         raise Zkg16Error(rc, "zkg16_circuit_prime")
-    c = SynthesizedCircuit(h, check_satisfied=True)
+    c = SynthesizedCircuit(h, check_satisfied=check_satisfied)
     c.j = j
     return c
 

@@ -125,13 +125,13 @@ def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
                 _detail=out, _circuit=circ)
 
 
-def prove_prime(dev, x, i, seed=7, keep_key=False):
+def prove_prime(dev, x, i, seed=7, keep_key=False, check_satisfied=False):
     """-> the reference's ProveOutput fields of the prime handler (prime_snark.rs:36-47): search j in 0..=i for the first
     hash(x + j) mod 2^20 that passes the Fermat test, build PrimeCircuit for it, circuit-specific setup, prove."""
     found = prime_search(x, i)
     if not found["found"]:
         return dict(proof="", j=0, num_constraints=0, num_variables=0, setup_time=0.0, proving_time=0.0, found_prime=False, prime_num="", vk="")
-    circ = prime_circuit(x, found["j"], search=False)
+    circ = prime_circuit(x, found["j"], search=False, check_satisfied=check_satisfied)
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), j=found["j"], num_constraints=circ.num_constraints,
                 num_variables=circ.num_vars, setup_time=out["setup_time"], proving_time=out["proving_time"], found_prime=True,
@@ -142,7 +142,7 @@ def prove_prime(dev, x, i, seed=7, keep_key=False):
 def verify_prime(vk, x, j, proof_b64):
     """Mirror of verify_prime (prime_snark.rs:165-206): the verifier re-synthesizes PrimeCircuit for (x, j) to recover the
     public inputs (x and the 256 digest bits), then checks the proof."""
-    circ = prime_circuit(x, j, search=False)
+    circ = prime_circuit(x, j, search=False, check_satisfied=False)
     return verify_proof(vk, circ.public_inputs, proof_b64)
 
 
