@@ -141,7 +141,6 @@ struct LaneLease {
                     if (!root->lane_busy[i]) { idx = i; return true; }
                 return false;
             });
-            if (idx > 0 && (int)root->lanes.size() < idx) root->lanes.resize(idx);
             if (idx > 0 && !root->lanes[idx - 1]) {
                 ZK_HIP(hipSetDevice(root->device));
                 auto l = std::make_unique<zkg16_ctx>();
@@ -181,7 +180,7 @@ struct LaneLease {
     LaneLease(const LaneLease &) = delete;
     LaneLease &operator=(const LaneLease &) = delete;
 };
-zkg16_ctx *lane_of(zkg16_ctx *root, int idx) { return idx <= 0 || idx > (int)root->lanes.size() || !root->lanes[idx - 1] ? root : root->lanes[idx - 1].get(); }
+zkg16_ctx *lane_of(zkg16_ctx *root, int idx) { return idx <= 0 || idx > 7 || !root->lanes[idx - 1] ? root : root->lanes[idx - 1].get(); }
 // the proving entry points: `ctx` is rebound to the leased lane for the body, `root` keeps the handle maps
 #define ZK_LANE_BEGIN(ctx)                        \
     if (!(ctx)) return ZKG16_ERR_BAD_ARG;         \
@@ -779,10 +778,12 @@ void zkg16_destroy(zkg16_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &l : ctx->lanes)
         if (l) {
-            std::lock_guard<std::mutex> lk(l->mu);      // a proof still running on that lane finishes first
-            teardown(l.get());
+            {
+                std::lock_guard<std::mutex> lk(l->mu);      // a proof still running on that lane finishes first
+                teardown(l.get());
+            }
+            l.reset();
         }
-    ctx->lanes.clear();
     teardown(ctx);
     ctx->pks.clear();
     ctx->r1cs.clear();

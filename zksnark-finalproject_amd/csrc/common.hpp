@@ -241,7 +241,7 @@ struct zkg16_ctx {
     // lane's workspaces, not by a second copy of the key and its window tables).  Lane 0 is the root itself; further lanes are
     // created when a second caller arrives while the first is still proving.
     zkg16_ctx *root = nullptr;
-    std::vector<std::unique_ptr<zkg16_ctx>> lanes;                // root: lanes 1 ..
+    std::unique_ptr<zkg16_ctx> lanes[7];                          // root: lanes 1 .. 7, created on first use (fixed slots: readers never see a resize)
     std::mutex lane_mu;
     std::condition_variable lane_cv;
     bool lane_busy[8] = {false, false, false, false, false, false, false, false};
