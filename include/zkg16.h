@@ -326,6 +326,7 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
  *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
+ *   "fixed_base_bits" window width of the setup's fixed-base multiplications (0 = by batch size; 16 / 18 / 20 = two-level tables)
  *   "g2_lazy"        G2 accumulation's Fq2 products: 0 / 1 (default) two fused two-product reductions with operands parked in LDS, 2 = Karatsuba
  *   "lanes"          proofs this ctx runs at a time (1..8, default 2): see the note on re-entrancy at the top
  *   "matrix_parts"   zkg16_prove_matrix: slices of the host sponges the proof is fed in (0 = five growing slices, k = k equal ones; 1 = assignment first, then the proof)

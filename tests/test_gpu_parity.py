@@ -72,15 +72,24 @@ def test_ntt_three_pass(dev, oracle, log_n):
 
 
 # ---------------------------------------------------------------------------------------------- fixed base / MSM
-def test_fixed_base_vs_oracle(dev, oracle):
+@pytest.mark.parametrize("bits", [0, 5, 14, 16, 18])
+def test_fixed_base_vs_oracle(dev, oracle, bits):
+    """Window widths by batch size (0), a narrow and the widest ladder-built table, and the two-level tables a large key's
+    batches use (16, 18: fixed_base_combine_kernel), forced here on a small batch; digits on either side of each window and
+    half-window boundary."""
     rng = random.Random(5)
-    ks = [0, 1, 2, 255, 256, P.R_MOD - 1] + [P.rand_fr(rng) for _ in range(200)]
+    ks = [0, 1, 2, 255, 256, 511, 512, (1 << 16) - 1, 1 << 16, (1 << 18) - 1, 1 << 18, (1 << 9) << 18, ((1 << 9) - 1) << 18 | 1,
+          (1 << 8) << 16, P.R_MOD - 1] + [P.rand_fr(rng) for _ in range(200)]
     sc = fr_canon_vec(ks)
-    for group, gen in (("g1", G1_GEN_LIMBS), ("g2", G2_GEN_LIMBS)):
-        got, ginf = dev.fixed_base(group, gen, sc)
-        exp, einf = oracle.fixed_base(group, gen, sc)
-        assert np.array_equal(ginf, einf)
-        assert np.array_equal(got[einf == 0], exp[einf == 0])
+    dev.set_option("fixed_base_bits", bits)
+    try:
+        for group, gen in (("g1", G1_GEN_LIMBS), ("g2", G2_GEN_LIMBS)):
+            got, ginf = dev.fixed_base(group, gen, sc)
+            exp, einf = oracle.fixed_base(group, gen, sc)
+            assert np.array_equal(ginf, einf)
+            assert np.array_equal(got[einf == 0], exp[einf == 0])
+    finally:
+        dev.set_option("fixed_base_bits", 0)
 
 
 def _golden_msm_arrays(case, group, oracle):
@@ -578,7 +587,8 @@ def test_error_paths(dev):
     assert ok[0].any()                                                    # and the ctx still proves after the refusals
     dev.pk_free(ph3)
     dev.r1cs_free(rh3)
-    for name, v in (("lanes", 0), ("lanes", 9), ("matrix_parts", 9), ("g2_lazy", 3)):
+    for name, v in (("lanes", 0), ("lanes", 9), ("matrix_parts", 9), ("g2_lazy", 3), ("fixed_base_bits", 3), ("fixed_base_bits", 17),
+                    ("fixed_base_bits", 22)):
         with pytest.raises(Zkg16Error):
             dev.set_option(name, v)
 
@@ -616,7 +626,7 @@ def test_prove_reference_circuits(dev, oracle, kind):
     assert np.array_equal(proof[36:], oracle.point_mul("g1", meta["g1"], fr_canon(cc))[0])
 
 
-@pytest.mark.parametrize("kind", ["random3000", "matrix3"])
+@pytest.mark.parametrize("kind", ["random3000", "matrix3", "random3000-wide"])
 def test_setup_on_device_vs_oracle(dev, oracle, kind):
     """zkg16_setup (trapdoor -> proving key on the device) == the oracle's key for the same trapdoor and generators
     (ark-groth16 generator.rs semantics), and a proof under that key satisfies the Groth16 equation in the exponent."""
@@ -639,7 +649,11 @@ def test_setup_on_device_vs_oracle(dev, oracle, kind):
     trap = fr_mont_vec([trap_int[k] for k in ("tau", "alpha", "beta", "gamma", "delta")])
     rh = dev.r1cs_load(r1cs, nv)
     domain = 1 << max(r1cs["num_constraints"] + ni - 1, 0).bit_length()
-    pk, vk = dev.setup(rh, ni, nv, domain, trap, meta["g1"], meta["g2"])
+    dev.set_option("fixed_base_bits", 16 if kind.endswith("-wide") else 0)          # the two-level tables of a large key
+    try:
+        pk, vk = dev.setup(rh, ni, nv, domain, trap, meta["g1"], meta["g2"])
+    finally:
+        dev.set_option("fixed_base_bits", 0)
     for k in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
         inf_key = {"a_query": "a_inf", "b_g1_query": "b_g1_inf", "b_g2_query": "b_g2_inf", "l_query": "l_inf"}.get(k)
         if inf_key:

@@ -81,7 +81,7 @@ void copy_options(zkg16_ctx *dst, const zkg16_ctx *src) {
     dst->opt_window_bits_h = src->opt_window_bits_h; dst->opt_reduce_chunk = src->opt_reduce_chunk; dst->opt_wm_concurrent = src->opt_wm_concurrent;
     dst->opt_ntt_radix = src->opt_ntt_radix; dst->opt_ntt_xcd = src->opt_ntt_xcd; dst->opt_acc_debug = src->opt_acc_debug;
     dst->opt_sort_mode = src->opt_sort_mode; dst->opt_acc_pipeline = src->opt_acc_pipeline; dst->opt_fuse_pointwise = src->opt_fuse_pointwise;
-    dst->opt_matrix_parts = src->opt_matrix_parts; dst->opt_g2_lazy = src->opt_g2_lazy;
+    dst->opt_matrix_parts = src->opt_matrix_parts; dst->opt_g2_lazy = src->opt_g2_lazy; dst->opt_fixed_base_bits = src->opt_fixed_base_bits;
     dst->kernel_timing = src->kernel_timing; dst->kernel_timing_accumulate_only = src->kernel_timing_accumulate_only;
 }
 void create_streams(zkg16_ctx *ctx) {
@@ -878,6 +878,11 @@ int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "b_filter")) {           // B-side term list = the sorted full list minus the masked terms: 0 (default) with window tables, 1 always; 2: second sort
         if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
         ctx->opt_b_filter = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "fixed_base_bits")) {    // setup's fixed-base windows: 0 = by batch size, else 4..14 (ladder-built table) or 16 / 18 / 20 (two-level)
+        if (value != 0 && (value < 4 || value > 20 || (value > 14 && (value & 1)))) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_fixed_base_bits = (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "g2_lazy")) {            // G2 bucket accumulation: 0 / 1 (default) = Fq2 products as two fused two-product reductions (LDS-parked operands), 2 = Karatsuba with three

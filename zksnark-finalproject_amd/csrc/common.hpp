@@ -279,6 +279,7 @@ struct zkg16_ctx {
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
     int opt_acc_pipeline = 0;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product (default: neither)
+    int opt_fixed_base_bits = 0;                      // setup's fixed-base window width (0 = by batch size; even widths >= 16 are built in two levels)
     int opt_g2_lazy = 1;                              // G2 accumulation: Fq2 products with one reduction per component, operands parked in LDS (ffu.cuh: fq2u_mul_lazy)
     int opt_matrix_parts = 0;                         // zkg16_prove_matrix: gadget slices the assignment arrives in (0 = five growing slices, k = k equal ones, 1 = no overlap)
     int opt_fuse_pointwise = 1;                       // (ab - c)/Z on the load of the seventh transform (0: its own pass)

@@ -570,6 +570,22 @@ fixed_base_table_kernel(const Affine<typename FieldTraits<FU>::Sat> *win_bases /
     stv(table + id, acc);
 }
 
+// Wide windows in two levels: entry d = dh 2^k + dl of a 2k-bit window is half[2w + 1][dh] + half[2w][dl] — ONE addition on top of a
+// table of k-bit windows (whose entries cost a k-step ladder each), so a 20-bit table (13.6 M entries) costs about what an 11-bit
+// one did and the per-point cost of a large batch drops from 19 additions (14-bit windows) to 13.
+template <class FU>
+__global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
+fixed_base_combine_kernel(const Affine<FU> *half /* 2 nwin x (2^k - 1) */, XYZZ<FU> *full /* nwin x (2^(2k) - 1) */, int k, int nwin) {
+    const size_t per_full = ((size_t)1 << (2 * k)) - 1, per_half = ((size_t)1 << k) - 1;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nwin * per_full) return;
+    const size_t w = id / per_full, d = id % per_full + 1, dl = d & per_half, dh = d >> k;
+    XYZZ<FU> acc = XYZZ<FU>::inf();
+    if (dl) acc = XYZZ<FU>::from_affine(ldv(half + (2 * w) * per_half + (dl - 1)));
+    if (dh) xyzz_madd(acc, ldv(half + (2 * w + 1) * per_half + (dh - 1)), false);
+    stv(full + id, acc);
+}
+
 template <class FU>
 __global__ void __launch_bounds__(64, FieldTraits<FU>::g2 ? 1 : 2)
 fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XYZZ<FU> *out, int wbits, int nwin) {
@@ -586,7 +602,7 @@ fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XY
         const uint64_t two = (uint64_t)k[bit >> 5] | ((uint64_t)k[(bit >> 5) + 1] << 32);
         const uint32_t d = (uint32_t)(two >> (bit & 31)) & (uint32_t)per;
         if (d) {
-            const Affine<FU> p = ldv(table + (size_t)w * per + (d - 1));
+            const Affine<FU> p = ldv(table + (size_t)w * (size_t)per + (d - 1));
             xyzz_madd(acc, p, false);
         }
     }
@@ -1199,9 +1215,16 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
                            size_t n, const AffineSegs<FU> &segs, bool sync = true) {
     using FS = typename FieldTraits<FU>::Sat;
     if (n == 0) return;
-    // 8-bit windows (32 additions per point, an 8,160-entry table) for small batches, 12-bit ones (22 additions, 90,090 entries:
-    // 10 / 20 MB, L2- and MALL-resident) once the batch is worth the larger table
-    const int wbits = n >= ((size_t)1 << 21) ? 14 : n >= ((size_t)1 << 17) ? 12 : 8;
+    // 8-bit windows (32 additions per point, an 8,160-entry table) for small batches, 12- and 14-bit ones (22 / 19 additions) once
+    // the batch is worth the larger table, and for the batches of a large key 16 / 18 / 20 bits (16 / 15 / 13 additions) built in
+    // two levels (fixed_base_combine_kernel).  128x128 key: 51.5 M G1 points at 20 bits (1.5 GB table, 13 instead of 19 additions
+    // each: 309 M additions saved for ~20 M spent on the table), 8.7 M G2 points at 18 bits.  Option "fixed_base_bits" forces a width.
+    constexpr bool g2 = FieldTraits<FU>::g2;
+    int wbits = n >= ((size_t)1 << 21) ? 14 : n >= ((size_t)1 << 17) ? 12 : 8;
+    if (!g2) { if (n >= ((size_t)1 << 25)) wbits = 20; else if (n >= ((size_t)1 << 23)) wbits = 18; else if (n >= ((size_t)1 << 22)) wbits = 16; }
+    else { if (n >= ((size_t)1 << 23)) wbits = 18; else if (n >= ((size_t)1 << 22)) wbits = 16; }
+    if (ctx->opt_fixed_base_bits) wbits = ctx->opt_fixed_base_bits;
+    const bool two_level = wbits >= 16;             // even widths only (checked by the option)
     const int nwin = (256 + wbits - 1) / wbits;
     const size_t tab_n = (size_t)nwin * (((size_t)1 << wbits) - 1);
     FixedBaseCache::Entry *ent = nullptr;
@@ -1215,40 +1238,53 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
     }
     ent->stamp = ++cache.clock;
     if (miss) {
-        // the 32 window bases 2^(8w) * base as affine points, one host inversion for all of them
-        std::vector<XYZZ<FS>> wx(nwin);
+        // the ladder-built table: `lb`-bit windows, `lw` of them (the table itself, or the half-width level of a two-level one)
+        const int lb = two_level ? wbits / 2 : wbits, lw = two_level ? 2 * nwin : nwin;
+        const size_t ltab_n = (size_t)lw * (((size_t)1 << lb) - 1);
+        // the window bases 2^(lb w) * base as affine points, one host inversion for all of them
+        std::vector<XYZZ<FS>> wx(lw);
         XYZZ<FS> cur = XYZZ<FS>::from_affine(base);
-        for (int w = 0; w < nwin; w++) {
+        for (int w = 0; w < lw; w++) {
             wx[w] = cur;
-            for (int q = 0; q < wbits; q++) cur = xyzz_dbl(cur);
+            for (int q = 0; q < lb; q++) cur = xyzz_dbl(cur);
         }
-        std::vector<Affine<FS>> wb(nwin, Affine<FS>::inf());
-        std::vector<FS> pre(nwin);
+        std::vector<Affine<FS>> wb(lw, Affine<FS>::inf());
+        std::vector<FS> pre(lw);
         FS acc = FS::one();
-        for (int w = 0; w < nwin; w++) {
+        for (int w = 0; w < lw; w++) {
             pre[w] = acc;
             if (!wx[w].is_inf()) acc = f_mul(acc, f_mul(wx[w].zz, wx[w].zzz));
         }
         FS inv = f_inv(acc);
-        for (int w = nwin - 1; w >= 0; w--) {
+        for (int w = lw - 1; w >= 0; w--) {
             if (wx[w].is_inf()) continue;
             const FS dinv = f_mul(inv, pre[w]);
             inv = f_mul(inv, f_mul(wx[w].zz, wx[w].zzz));
             wb[w] = Affine<FS>{f_mul(wx[w].x, f_mul(dinv, wx[w].zzz)), f_mul(wx[w].y, f_mul(dinv, wx[w].zz))};
         }
         DevBuf &d_wb = cache.win_bases, &d_xyzz = cache.table_xyzz;      // kept in the cache: nothing here has to outlive a sync
-        d_wb.ensure(nwin * sizeof(Affine<FS>));
-        d_xyzz.ensure(tab_n * sizeof(XYZZ<FU>));
+        d_wb.ensure(lw * sizeof(Affine<FS>));
+        d_xyzz.ensure((two_level ? tab_n : ltab_n) * sizeof(XYZZ<FU>));
         ent->table.ensure(tab_n * sizeof(Affine<FU>));
+        DevBuf half_tab;
+        if (two_level) half_tab.alloc(ltab_n * sizeof(Affine<FU>));
         ent->wbits = wbits;
-        ZK_HIP(hipMemcpy(d_wb.p, wb.data(), nwin * sizeof(Affine<FS>), hipMemcpyHostToDevice));       // 3-6 KB, from a host vector that goes away
-        hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((unsigned)((tab_n + 63) / 64)), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
-                           d_xyzz.as<XYZZ<FU>>(), wbits, nwin);
+        ZK_HIP(hipMemcpy(d_wb.p, wb.data(), lw * sizeof(Affine<FS>), hipMemcpyHostToDevice));       // 3-6 KB, from a host vector that goes away
+        hipLaunchKernelGGL(fixed_base_table_kernel<FU>, dim3((unsigned)((ltab_n + 63) / 64)), dim3(64), 0, ctx->stream, d_wb.as<Affine<FS>>(),
+                           d_xyzz.as<XYZZ<FU>>(), lb, lw);
         ZK_HIP(hipGetLastError());
         AffineSegs<FU> ts{};
         ts.n = 1;
-        ts.out_u[0] = ent->table.as<Affine<FU>>();
-        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), tab_n, cache.pref, ts);
+        ts.out_u[0] = two_level ? half_tab.as<Affine<FU>>() : ent->table.as<Affine<FU>>();
+        batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), ltab_n, cache.pref, ts);
+        if (two_level) {
+            hipLaunchKernelGGL(fixed_base_combine_kernel<FU>, dim3((unsigned)((tab_n + 63) / 64)), dim3(64), 0, ctx->stream, half_tab.as<Affine<FU>>(),
+                               d_xyzz.as<XYZZ<FU>>(), lb, nwin);
+            ZK_HIP(hipGetLastError());
+            ts.out_u[0] = ent->table.as<Affine<FU>>();
+            batch_affine_run<FU>(ctx, d_xyzz.as<XYZZ<FU>>(), tab_n, cache.pref, ts);
+            ZK_HIP(hipStreamSynchronize(ctx->stream));          // half_tab goes out of scope
+        }
         ent->key.assign(reinterpret_cast<const uint8_t *>(&base), reinterpret_cast<const uint8_t *>(&base) + sizeof base);
     }
     cache.sums.ensure(n * sizeof(XYZZ<FU>));
