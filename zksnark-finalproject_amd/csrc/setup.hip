@@ -7,6 +7,8 @@
 //   query scalars               a = u, b = v, l = (beta u + alpha v + w)/delta, gamma_abc = (...)/gamma, h_i = tau^i Z(tau)/delta
 //   query points                fixed-base batch multiplication [scalar] g      [msm.hip fixed_base_*]
 // The caller draws tau, alpha, beta, gamma, delta and the two generators exactly as upstream does (from its rng).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace zk {
@@ -45,17 +47,28 @@ __global__ void __launch_bounds__(256) setup_col_offsets_kernel(const uint2 *sor
     offsets[k] = (uint32_t)lo;
 }
 // out[k] = sum over the entries of column k of coeff[e] * L[row[e]]   (+ L[nc + k] for k < num_instance when add_inputs)
-// Columns longer than COL_HEAVY entries (the constant-one column of a Poseidon-heavy circuit holds ~10^5) are queued for
-// setup_col_sum_heavy_kernel instead of being walked by one lane.
+// Columns longer than COL_HEAVY entries are not walked by one lane: they are queued as slices of COL_SLICE entries (the
+// constant-one column of the 128x128 MatrixCircuit holds millions of entries — one block walking it alone took 15.7 ms per
+// matrix, 47 ms of a 250 ms setup), one block per slice (setup_col_sum_heavy_kernel), and the slices of a column are added up by
+// setup_col_sum_gather_kernel.  Queue: heavy[0] = number of slices, then (column, slice index, slices of that column) triples;
+// the slices of one column are contiguous (one atomicAdd reserves them).
 constexpr uint32_t COL_HEAVY = 1024;          // a lane walks up to this many entries itself (~1 ms)
+constexpr uint32_t COL_SLICE = 8192;          // entries per queued slice: 32 per lane of a 256-lane block
+static size_t col_queue_slots(size_t nnz) { return nnz / COL_HEAVY + nnz / COL_SLICE + 2; }      // heavy columns + full slices, rounded up
 __global__ void __launch_bounds__(256) setup_col_sum_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
                                                             const Fr *L, size_t ncols, size_t nc, size_t num_instance, int add_inputs, Fr *out,
-                                                            uint32_t *heavy /* [0] = count, then column ids: room for every column */) {
+                                                            uint32_t *heavy) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncols) return;
     const uint32_t lo = offsets[k], hi = offsets[k + 1];
     if (hi - lo > COL_HEAVY) {
-        heavy[1 + atomicAdd(heavy, 1u)] = (uint32_t)k;
+        const uint32_t slices = (hi - lo + COL_SLICE - 1) / COL_SLICE;
+        const uint32_t at = atomicAdd(heavy, slices);
+        for (uint32_t j = 0; j < slices; j++) {
+            heavy[1 + 3 * (at + j)] = (uint32_t)k;
+            heavy[2 + 3 * (at + j)] = j;
+            heavy[3 + 3 * (at + j)] = slices;
+        }
         return;
     }
     Fr acc = Fr::zero();
@@ -66,15 +79,14 @@ __global__ void __launch_bounds__(256) setup_col_sum_kernel(const uint2 *sorted,
     if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
     st_fr(out + k, acc);
 }
-// one 256-lane block per queued column: strided partial sums, then an LDS tree
+// one 256-lane block per queued slice: strided partial sums, then an LDS tree; partial[q] = the slice's sum
 __global__ void __launch_bounds__(256) setup_col_sum_heavy_kernel(const uint2 *sorted, const uint32_t *offsets, const uint32_t *rowid, const Fr *coeff,
-                                                                  const Fr *L, size_t nc, size_t num_instance, int add_inputs, Fr *out,
-                                                                  const uint32_t *heavy) {
+                                                                  const Fr *L, const uint32_t *heavy, Fr *partial) {
     __shared__ uint32_t part[8][256];
     const uint32_t cnt = heavy[0];
     for (uint32_t q = blockIdx.x; q < cnt; q += gridDim.x) {
-        const uint32_t k = heavy[1 + q];
-        const uint32_t lo = offsets[k], hi = offsets[k + 1];
+        const uint32_t k = heavy[1 + 3 * q], j = heavy[2 + 3 * q];
+        const uint32_t lo = offsets[k] + j * COL_SLICE, end = offsets[k + 1], hi = end - lo > COL_SLICE ? lo + COL_SLICE : end;
         Fr acc = Fr::zero();
         for (uint32_t p = lo + threadIdx.x; p < hi; p += 256) {
             const uint32_t e = sorted[p].x;
@@ -91,11 +103,21 @@ __global__ void __launch_bounds__(256) setup_col_sum_heavy_kernel(const uint2 *s
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
-            st_fr(out + k, acc);
-        }
+        if (threadIdx.x == 0) st_fr(partial + q, acc);
         __syncthreads();
+    }
+}
+// one lane per queued slice; the lane of a column's slice 0 adds the column's partials (at most nnz / COL_SLICE of them)
+__global__ void __launch_bounds__(256) setup_col_sum_gather_kernel(const uint32_t *heavy, const Fr *partial, const Fr *L, size_t nc, size_t num_instance,
+                                                                   int add_inputs, Fr *out) {
+    const uint32_t cnt = heavy[0];
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < cnt; q += gridDim.x * blockDim.x) {
+        if (heavy[2 + 3 * q] != 0) continue;
+        const uint32_t k = heavy[1 + 3 * q], slices = heavy[3 + 3 * q];
+        Fr acc = ld_fr(partial + q);
+        for (uint32_t j = 1; j < slices; j++) acc = fp_add(acc, ld_fr(partial + q + j));
+        if (add_inputs && k < num_instance) acc = fp_add(acc, ld_fr(L + nc + k));
+        st_fr(out + k, acc);
     }
 }
 // lg[k] = (beta u_k + alpha v_k + w_k) * (k < num_instance ? gamma^-1 : delta^-1)
@@ -123,7 +145,8 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
 
     // u, v, w: per-matrix column sums
     DevBuf uvw[3];
-    DevBuf keys, sorted, rowid, coloff, sort_temp, heavy((1 + nv) * sizeof(uint32_t));
+    const size_t queue_slots = col_queue_slots(std::max(m.nnz[0], std::max(m.nnz[1], m.nnz[2])));
+    DevBuf keys, sorted, rowid, coloff, sort_temp, heavy((1 + 3 * queue_slots) * sizeof(uint32_t)), partial(queue_slots * sizeof(Fr));
     unsigned key_bits = 1;
     while (((size_t)1 << key_bits) <= nv) key_bits++;
     for (int k = 0; k < 3; k++) {
@@ -144,8 +167,10 @@ void setup_run(zkg16_ctx *ctx, const R1csDev &m, const Fr trap[5], const G1Affin
         hipLaunchKernelGGL(setup_col_sum_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, sorted.as<uint2>(),
                            coloff.as<uint32_t>(), rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nv, nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>(),
                            heavy.as<uint32_t>());
-        hipLaunchKernelGGL(setup_col_sum_heavy_kernel, dim3(512), dim3(256), 0, ctx->stream, sorted.as<uint2>(), coloff.as<uint32_t>(),
-                           rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), nc, ni, k == 0 ? 1 : 0, uvw[k].as<Fr>(), heavy.as<uint32_t>());
+        hipLaunchKernelGGL(setup_col_sum_heavy_kernel, dim3(2048), dim3(256), 0, ctx->stream, sorted.as<uint2>(), coloff.as<uint32_t>(),
+                           rowid.as<uint32_t>(), m.cf[k].as<Fr>(), L.as<Fr>(), heavy.as<uint32_t>(), partial.as<Fr>());
+        hipLaunchKernelGGL(setup_col_sum_gather_kernel, dim3(64), dim3(256), 0, ctx->stream, heavy.as<uint32_t>(), partial.as<Fr>(), L.as<Fr>(), nc, ni,
+                           k == 0 ? 1 : 0, uvw[k].as<Fr>());
         ZK_HIP(hipGetLastError());
     }
     DevBuf lg(nv * sizeof(Fr));
