@@ -933,6 +933,42 @@ def test_full_size_request_verifies_with_tables(dev):
         f(h)
 
 
+def test_headline_size_equals_oracle(dev, oracle):
+    """The headline configuration against the oracle, bit for bit: MatrixCircuit 128x128 (10,706,932 constraints, domain 2^24)
+    with random full-range inputs — key from the device setup (host copy), the plain proof, the streamed request
+    (zkg16_prove_matrix, assignment from the device) and the proof with window tables all == the CPU oracle's proof for the same
+    key, r, s, matrices and assignment (the oracle takes ~1.5 minutes on 16 threads for this size)."""
+    from zksnark_finalproject_amd.circuits import matrix_circuit
+    from zksnark_finalproject_amd.device import scalar_mul
+    from zksnark_finalproject_amd.workloads import g1_generator, g2_generator
+    n = 128
+    rng_np = np.random.default_rng(77)
+    a = rng_np.integers(0, 1 << 63, size=(n, n), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    b = rng_np.integers(0, 1 << 63, size=(n, n), dtype=np.uint64)
+    circ = matrix_circuit(a, b)
+    assert circ.num_constraints == 10706932 and circ.domain == 1 << 24
+    rng = random.Random(1128)
+    trap = np.stack([fr_mont(P.rand_fr(rng)) for _ in range(5)])
+    k = np.array([rng.getrandbits(62) for _ in range(4)], dtype=np.uint64)
+    g1, g2 = scalar_mul("g1", g1_generator(), k)[0], scalar_mul("g2", g2_generator(), k)[0]
+    rh = dev.r1cs_load(circ.r1cs, circ.num_vars)
+    pk, vk = dev.setup(rh, circ.num_instance, circ.num_vars, circ.domain, trap, g1, g2)
+    ph = dev.pk_load(pk, circ.num_instance)
+    wh = dev.witness_load(circ.z)
+    r, s = fr_mont(P.rand_fr(rng)), fr_mont(P.rand_fr(rng))
+    plain = dev.prove_resident(ph, rh, wh, r, s)
+    streamed = dev.prove_matrix(ph, rh, a, b, r, s)
+    dev.pk_precompute(ph)
+    tabled = dev.prove_resident(ph, rh, wh, r, s)
+    for f, h in ((dev.pk_free, ph), (dev.r1cs_free, rh), (dev.witness_free, wh)):
+        f(h)
+    oracle.set_threads(min(os.cpu_count() or 1, 16))
+    eproof, einf = oracle.prove(pk, r, s, circ.r1cs, circ.z)
+    assert list(einf) == [0, 0, 0]
+    for name, got in (("plain", plain), ("streamed", streamed[:2]), ("tabled", tabled)):
+        assert np.array_equal(got[1], einf) and np.array_equal(got[0], eproof), name
+
+
 @pytest.mark.parametrize("n,tables,parts", [(8, False, 0), (33, False, 0), (46, True, 0), (46, False, 8), (46, True, 1), (128, True, 0)])
 def test_prove_matrix_streamed_equals_two_step(dev, n, tables, parts):
     """zkg16_prove_matrix: the assignment arrives on the device in parts while the z-side MSMs already run on the parts that exist
