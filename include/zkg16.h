@@ -293,13 +293,14 @@ ZKG16_API int zkg16_bench_msm(zkg16_ctx *ctx, int group /*1|2*/, const uint64_t 
                     uint64_t *out_affine, uint8_t *out_inf);
 
 /* ---- instrumentation --------------------------------------------------------------------------- */
-/* Times of the last prove on this ctx, in ms (returns the number of entries written, up to 20):
+/* Times of the last prove on this ctx, in ms (returns the number of entries written, up to 22):
  * [0] unused, [1] witness map (device; upstream span "R1CS to QAP witness map"), [2] scalar digits + bucket scatter of both scalar
  * vectors (device), [3..7] host-observed completion gaps of H, L, A, B1, B2 in collection order (NOT a breakdown: the first gap
  * holds most of the device time), [8] host tail ("Finish C"), [9] total wall;
  * [10..14] device time of the bucket accumulation + fix-ups of H, L, A, B1, B2 and [15..19] of their bucket reductions, from event
  * pairs on the streams they ran on: upstream's "Compute C" = H + L, "Compute A", "Compute B in G1", "Compute B in G2"
- * (ark-groth16 prover.rs).  MSMs overlap each other and the witness map, so the device times sum to more than [9]. */
+ * (ark-groth16 prover.rs).  MSMs overlap each other and the witness map, so the device times sum to more than [9];
+ * [20] host time of combining H's window sums (after the proof's last device event), [21] of the other four MSMs' (under H's device work). */
 ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
 /* Lengths of the sorted (scalar, window) term lists of the last proof on this ctx = mixed additions of each MSM that walks the list:
  * [0] the z list (A and L), [1] the B list (B1 and B2; 0 = they used the z list), [2] the h list.  Synchronises the ctx. */
@@ -326,6 +327,7 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
  *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
+ *   "collect_threads" host combination of the z-side MSMs' window sums: 0 = own threads for plain keys, 1 = always, 2 = never
  *   "fixed_base_bits" window width of the setup's fixed-base multiplications (0 = by batch size; 16 / 18 / 20 = two-level tables)
  *   "g2_lazy"        G2 accumulation's Fq2 products: 0 / 1 (default) two fused two-product reductions with operands parked in LDS, 2 = Karatsuba
  *   "lanes"          proofs this ctx runs at a time (1..8, default 2): see the note on re-entrancy at the top

@@ -107,12 +107,14 @@ def test_msm_golden(dev, oracle, group):
     enc = g1_limbs if group == "g1" else g2_limbs
     for case in load("msm_kat.json"):
         bases, inf, sc = _golden_msm_arrays(case, group, oracle)
-        for c in (0, 4, 7):
+        for c, mode in ((0, 0), (4, 0), (7, 0), (5, 5), (9, 5), (13, 5)):           # mode 5: the bit-sliced bucket reduction on every window
             dev.set_option("window_bits", c)
+            dev.set_option("reduce_mode", mode)
             got, ginf = dev.msm(group, bases, sc, inf)
             exp, einf = enc(case["expected_" + group])
-            assert ginf == einf and (einf or np.array_equal(got, exp)), (case["name"], c)
+            assert ginf == einf and (einf or np.array_equal(got, exp)), (case["name"], c, mode)
     dev.set_option("window_bits", 0)
+    dev.set_option("reduce_mode", 0)
 
 
 def _random_points(dev, group, n, seed):
@@ -333,9 +335,10 @@ def test_prove_random_vs_oracle_and_exponent(dev, oracle):
     proof2, inf2 = dev.prove_finish(ph, fr_mont(r), fr_mont(s), np.array(parts), np.array(pinf))
     assert np.array_equal(proof2, proof) and np.array_equal(inf2, inf)
     # every scheduling / tuning option leaves the proof bit-identical (the measured alternatives)
-    for opt, vals in (("reduce_mode", (1, 2, 4, 0)), ("fixup_aux", (1, 0)), ("g1_waves", (1, 3, 4, 0)), ("window_bits_h", (9, 0)),
+    for opt, vals in (("reduce_mode", (1, 2, 4, 5, 6, 0)), ("fixup_aux", (1, 0)), ("g1_waves", (1, 3, 4, 0)), ("window_bits_h", (9, 0)),
                       ("window_bits", (2, 3, 7, 11, 17, 0)), ("reduce_chunk", (4, 16, 0)), ("wm_concurrent", (0, -1)), ("fuse_pointwise", (0, 1)),
-                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0)), ("b_filter", (1, 2, 0)), ("g2_lazy", (2, 0))):
+                      ("ntt_mode", (0, 1)), ("ntt_radix", (4, 2)), ("ntt_xcd", (2, 1)), ("sort_mode", (1, 0)), ("acc_pipeline", (3, 1, 2, 0)), ("b_filter", (1, 2, 0)), ("g2_lazy", (2, 0)),
+                      ("collect_threads", (1, 2, 0))):
         for v in vals:
             dev.set_option(opt, v)
             p3, i3 = dev.prove_resident(ph, rh, wh, fr_mont(r), fr_mont(s))

@@ -8,6 +8,8 @@
 #include <functional>
 #include <thread>
 
+#include <exception>
+
 #include "common.hpp"
 
 using namespace zk;
@@ -82,6 +84,7 @@ void copy_options(zkg16_ctx *dst, const zkg16_ctx *src) {
     dst->opt_ntt_radix = src->opt_ntt_radix; dst->opt_ntt_xcd = src->opt_ntt_xcd; dst->opt_acc_debug = src->opt_acc_debug;
     dst->opt_sort_mode = src->opt_sort_mode; dst->opt_acc_pipeline = src->opt_acc_pipeline; dst->opt_fuse_pointwise = src->opt_fuse_pointwise;
     dst->opt_matrix_parts = src->opt_matrix_parts; dst->opt_g2_lazy = src->opt_g2_lazy; dst->opt_fixed_base_bits = src->opt_fixed_base_bits;
+    dst->opt_collect_threads = src->opt_collect_threads;
     dst->kernel_timing = src->kernel_timing; dst->kernel_timing_accumulate_only = src->kernel_timing_accumulate_only;
 }
 void create_streams(zkg16_ctx *ctx) {
@@ -503,9 +506,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
     double tprev = now_ms();
     auto lap = [&](int idx) { const double t = now_ms(); ctx->timings[idx] = (float)(t - tprev); tprev = t; };
     const bool early = pk.full;
-    if (z_side) {
-        out.b2 = msm_g2_collect(ctx, ctx->slots[0]); lap(7);
-        out.l = msm_g1_collect(ctx, ctx->slots[2]); lap(4);
+    auto collect_b2 = [&] { out.b2 = msm_g2_collect(ctx, ctx->slots[0]); };
+    auto collect_l = [&] { out.l = msm_g1_collect(ctx, ctx->slots[2]); };
+    auto collect_a = [&] {
         out.a = msm_g1_collect(ctx, ctx->slots[3]);
         if (early) {
             G1XYZZ A = out.a;
@@ -513,22 +516,69 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
             const Fr sc = fp_from_mont(s);
             out.s_a = xyzz_mul(A, sc.l);
         }
-        lap(5);
+    };
+    auto collect_b1 = [&] {
         out.b1 = msm_g1_collect(ctx, ctx->slots[4]);
         if (early) {
             G1XYZZ B1 = out.b1;
             xyzz_madd(B1, pk.beta_g1, false);
             const Fr rc_ = fp_from_mont(r);
             out.r_b1 = xyzz_mul(B1, rc_.l);
-            out.have_early = true;
         }
-        lap(6);
+    };
+    // A plain key's MSMs come back as one sum per window (and per weight bit with the bit-sliced reduction): ~0.3 ms of host
+    // additions per G1 MSM and ~1 ms for the G2 one.  One after the other they outlast the device on small and mid-size circuits
+    // (8x8: 2.4 ms of host work in a 4.4 ms proof), so each collect gets its own thread: it waits for its MSM's event, then combines.
+    const bool threaded = z_side && ctx->opt_collect_threads != 0 &&
+                          (ctx->opt_collect_threads == 1 || ctx->slots[0].nwin > 1 || ctx->slots[2].nwin > 1);
+    if (z_side && threaded) {
+        std::exception_ptr err[4];
+        {
+            ThreadGroup tg;
+            const int device = ctx->device;
+            auto guarded = [&err, device](int i, auto &job) {
+                return [&err, device, i, &job] {
+                    try {
+                        (void)hipSetDevice(device);
+                        job();
+                    } catch (...) {
+                        err[i] = std::current_exception();
+                    }
+                };
+            };
+            tg.run(guarded(0, collect_b2));
+            tg.run(guarded(1, collect_l));
+            tg.run(guarded(2, collect_a));
+            tg.run(guarded(3, collect_b1));
+            try {
+                if (nh) out.h = msm_g1_collect(ctx, ctx->slots[1]);
+                else ZK_HIP(hipStreamSynchronize(ctx->stream));
+            } catch (...) {
+                tg.join();
+                throw;
+            }
+            lap(3);
+            tg.join();
+        }
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
+        out.have_early = early;
+        ctx->timings[4] = ctx->timings[5] = ctx->timings[6] = 0;
+        lap(7);      // what the slowest z-side collect took beyond H's
     } else {
-        ctx->timings[4] = ctx->timings[5] = ctx->timings[6] = ctx->timings[7] = 0;
+        if (z_side) {
+            collect_b2(); lap(7);
+            collect_l(); lap(4);
+            collect_a(); lap(5);
+            collect_b1(); lap(6);
+            out.have_early = early;
+        } else {
+            ctx->timings[4] = ctx->timings[5] = ctx->timings[6] = ctx->timings[7] = 0;
+        }
+        if (nh) out.h = msm_g1_collect(ctx, ctx->slots[1]);
+        else ZK_HIP(hipStreamSynchronize(ctx->stream));
+        lap(3);
     }
-    if (nh) out.h = msm_g1_collect(ctx, ctx->slots[1]);
-    else ZK_HIP(hipStreamSynchronize(ctx->stream));
-    lap(3);
     float ms;
     // [1] witness map, [2] digits+sort of both vectors (device time); [3..7] host-observed completion gaps of H, L, A, B1, B2
     // (collected in the order B2, L, A, B1, H — the first gap contains most of the device time: NOT a breakdown);
@@ -548,6 +598,9 @@ void prove_device(zkg16_ctx *ctx, PkDev &pk, R1csDev &rc, WitnessDev &wit, const
             ctx->timings[15 + k] = red_ms;
         }
     }
+    // [20] host Horner of H's window sums (after the last device event of the proof: exposed), [21] of the other four (overlap H's device work)
+    ctx->timings[20] = nh ? ctx->slots[1].collect_host_ms : 0;
+    ctx->timings[21] = z_side ? ctx->slots[0].collect_host_ms + ctx->slots[2].collect_host_ms + ctx->slots[3].collect_host_ms + ctx->slots[4].collect_host_ms : 0;
     ctx->timings[0] = 0;
     ZK_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
     ctx->timings[1] = ms;
@@ -812,7 +865,8 @@ int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "reduce_mode")) {
-        if (value < 0 || value > 4) return ZKG16_ERR_BAD_ARG;      // 4 = classic everywhere (0 restores the default, 3)
+        // 4 = classic everywhere (0 restores the default, 3); 5 = bit-sliced wherever it applies; 6 = the default without the bit-sliced form
+        if (value < 0 || value > 6) return ZKG16_ERR_BAD_ARG;
         ctx->opt_reduce_mode = value == 0 ? 3 : (value == 4 ? 0 : (int)value);
         return ZKG16_OK;
     }
@@ -878,6 +932,11 @@ int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "b_filter")) {           // B-side term list = the sorted full list minus the masked terms: 0 (default) with window tables, 1 always; 2: second sort
         if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
         ctx->opt_b_filter = (int)value;
+        return ZKG16_OK;
+    }
+    if (!strcmp(name, "collect_threads")) {    // host combination of the MSMs' window sums: 0 = by key kind (threads for plain keys), 1 = always threaded, 2 = never
+        if (value < 0 || value > 2) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_collect_threads = value == 0 ? -1 : value == 2 ? 0 : 1;
         return ZKG16_OK;
     }
     if (!strcmp(name, "fixed_base_bits")) {    // setup's fixed-base windows: 0 = by batch size, else 4..14 (ladder-built table) or 16 / 18 / 20 (two-level)
@@ -1680,7 +1739,7 @@ int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap) {
     { std::lock_guard<std::mutex> lk(ctx->lane_mu); last = ctx->last_lane; }
     zkg16_ctx *l = lane_of(ctx, last);
     std::lock_guard<std::mutex> lk(l->mu);
-    const int n = cap < 20 ? cap : 20;
+    const int n = cap < 22 ? cap : 22;
     for (int i = 0; i < n; i++) ms[i] = l->timings[i];
     return n;
 }

@@ -212,6 +212,8 @@ struct MsmSlot {            // one in-flight MSM: written by the accumulate half
     alignas(16) unsigned char acc_args[128] = {0};
     unsigned acc_grid = 0;
     int two_level_k = 0;            // K of the work-efficient reduction when it was used for this MSM (0 = classic)
+    float collect_host_ms = 0;      // host part of msm_collect (the Horner over windows / weight bits) of the last MSM on this slot
+    int bit_sliced = 0;             // > 0: the bit-sliced reduction ran with this many weight bits (two_level_k = its chunk size)
     void *red_buckets = nullptr;
     size_t red_nb = 0;
 };
@@ -265,7 +267,7 @@ struct zkg16_ctx {
     int opt_window_bits = 0;
     int opt_min_seg = 0;                              // shortest per-lane run of sorted entries in an accumulation (0 = default)
     int opt_ntt_mode = 1;                             // 1: unsaturated (29-bit limb) butterflies, 0: saturated
-    int opt_reduce_mode = 3;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level, 2 = 1 except the proof's last MSM, 3 (default) = 2 from 16-bit windows on
+    int opt_reduce_mode = 3;                          // 0 classic (log-depth scan over all chunks), 1 work-efficient two-level, 2 = 1 except the proof's last MSM, 3 (default) = 2 from 16-bit windows on and bit-sliced for single bucket sets <= 2^19, 5 = bit-sliced wherever it applies
     int opt_b_filter = 0;                             // B-side term list filtered out of the full one: 0 = with window tables (default), 1 = always, 2 = never (second sort)
     int opt_spmv_dict = 0;                            // 0/1: coefficient dictionary in the SpMV (default); 2: plain kernel
     int opt_wm_first = -1;                            // see zkg16_set_option "wm_first"
@@ -279,6 +281,7 @@ struct zkg16_ctx {
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
     int opt_acc_pipeline = 0;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product (default: neither)
+    int opt_collect_threads = -1;                     // -1: the z-side MSMs' window sums are combined on their own host threads when the key is plain; 1 always; 0 never
     int opt_fixed_base_bits = 0;                      // setup's fixed-base window width (0 = by batch size; even widths >= 16 are built in two levels)
     int opt_g2_lazy = 1;                              // G2 accumulation: Fq2 products with one reduction per component, operands parked in LDS (ffu.cuh: fq2u_mul_lazy)
     int opt_matrix_parts = 0;                         // zkg16_prove_matrix: gadget slices the assignment arrives in (0 = five growing slices, k = k equal ones, 1 = no overlap)

@@ -20,6 +20,8 @@
 //
 // Arithmetic: 381-bit Montgomery on v_mad_u64_u32 — integer-ALU bound, not HBM bound: one mixed add is ~10 Fq
 // products (~3k VALU ops) per 96-B base gathered.  No MFMA (no dense contraction); LDS is used by the scan.
+#include <chrono>
+
 #include "common.hpp"
 
 namespace zk {
@@ -500,6 +502,38 @@ __global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_chunk_loca
     }
     stv(sums + id, run);
     stv(mom + id, acc);
+}
+
+// ---- the bit-sliced form (reduce_mode 5; the default for one bucket set of up to 2^19 buckets, i.e. keys with window tables).
+// The chains above are DEEP: ~70 dependent point additions for 2^16 buckets, and one G2 addition is ~70 us of one wave's
+// instruction stream — a 32x32 proof spent 6.2 of its 11.5 ms there with 2 % of the lanes busy.  Here, after chunk_local
+// (K = 4: 7 additions deep) the weights are cut by BIT:
+//   sum_c (c+1) S_c = sum_t 2^t T_t + 2^bits S_top,   T_t = sum of the S_c whose c+1 has bit t set   (c+1 <= 2^bits, = only for the top)
+// every T_t is a plain pairwise tree, all of them (and the tree of the M_c) side by side in ONE array of bits+1 pseudo-windows:
+// msm_bit_pairs_kernel forms the first level, msm_sum_step_kernel halves it; the host does the 2 bits + 3 operations of the
+// Horner over t (msm_collect).  Depth 7 + ~2 + log2(ns/2) additions instead of ~70; (bits+1) ns additions of work.
+template <class F>
+__global__ void __launch_bounds__(64, FieldTraits<F>::g2 ? 1 : 2) msm_bit_pairs_kernel(const XYZZ<F> *S, const XYZZ<F> *M, XYZZ<F> *out, size_t ns, int bits, int nwin) {
+    const size_t half = ns / 2;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)(bits + 1) * nwin * half) return;
+    const size_t t = id / ((size_t)nwin * half), rem = id - t * (size_t)nwin * half, w = rem / half, i = rem - w * half;
+    const size_t c0 = 2 * i, c1 = c0 + 1;
+    XYZZ<F> x;
+    if ((int)t == bits) {                                    // the moments' tree
+        x = ldv(M + w * ns + c0);
+        const XYZZ<F> y = ldv(M + w * ns + c1);
+        xyzz_add(x, y);
+    } else {
+        const bool take0 = ((c0 + 1) >> t) & 1, take1 = ((c1 + 1) >> t) & 1;
+        x = XYZZ<F>::inf();
+        if (take0) x = ldv(S + w * ns + c0);
+        if (take1) {
+            const XYZZ<F> y = ldv(S + w * ns + c1);
+            if (take0) xyzz_add(x, y); else x = y;
+        }
+    }
+    stv(out + id, x);
 }
 
 // ------------------------------------------------------------------------------------------------ representation changes
@@ -1040,13 +1074,38 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     // (slot.last_of_proof, set by the caller): the others overlap the next accumulation, where work, not depth, is what costs
     // default (3): mode 2 from 16-bit windows on (measured 128x128: 184.1 -> 182.5 ms; 32x32: no change; a 6,476-constraint proof
     // 3.6 -> 4.8 ms with it, so small windows keep the short chain)
-    const bool efficient = ctx->opt_reduce_mode == 1 || (ctx->opt_reduce_mode == 2 && !slot.last_of_proof) ||
-                           (ctx->opt_reduce_mode == 3 && !slot.last_of_proof && slot.c >= 16);
+    const int rmode = ctx->opt_reduce_mode >= 5 ? 3 : ctx->opt_reduce_mode;          // 5 / 6: the default with / without the bit-sliced form
+    const bool efficient = rmode == 1 || (rmode == 2 && !slot.last_of_proof) || (rmode == 3 && !slot.last_of_proof && slot.c >= 16);
     slot.two_level_k = (efficient && kk >= 2 && nchunks >= 2 * (size_t)kk2) ? kk : 0;
-    const size_t nout = (slot.two_level_k ? 2 : 1) * (size_t)plan.nwin;
-    slot.red_a.ensure(tot * psz);
-    slot.red_b.ensure(tot * psz);
-    slot.red_c.ensure(tot * psz);
+    // bit-sliced: bucket sets of a size where depth, not work, is what the reduction costs — one set of up to 2^19 buckets (window
+    // tables), or the windows of a plain key from 13-bit windows on while they hold up to 2^19 buckets together (the host combines
+    // (2 bits + 3) nwin sums: ~0.5 us per G1 and ~1.4 us per G2 operation, which smaller circuits cannot hide — 8x8: 4.4 -> 5.3 ms)
+    slot.bit_sliced = 0;
+    const bool pow2 = (plan.nb & (plan.nb - 1)) == 0;
+    const bool bs_auto = ctx->opt_reduce_mode == 3 && (plan.nwin == 1 ? plan.nb >= 256 && plan.nb <= ((size_t)1 << 19) : plan.nb >= 4096 && tb <= ((size_t)1 << 19));
+    if (pow2 && plan.nb >= 8 && (ctx->opt_reduce_mode == 5 || bs_auto)) {
+        auto log2z = [](size_t v) { int l = 0; while (((size_t)1 << l) < v) l++; return l; };
+        // chunk size by depth in dependent additions: 2K - 1 in chunk_local, the first tree level in rounds of the resident lanes (a G2
+        // wave fills a SIMD, two G1 waves do; the following levels add about as much again), then one per halving
+        const double resident = FieldTraits<F>::g2 ? 65536.0 : 131072.0;
+        int kb = 2;
+        double best = 1e30;
+        for (int k = 2; k <= 16 && (size_t)k * 4 <= plan.nb; k <<= 1) {
+            const size_t ns = plan.nb / k;
+            const double rounds = (double)(log2z(ns) + 1) * plan.nwin * (ns / 2) / resident;
+            const double depth = 2 * k - 1 + 2 * (rounds > 1 ? rounds : 1) + log2z(ns) - 1;
+            if (depth < best) { best = depth; kb = k; }
+        }
+        if (ctx->opt_reduce_chunk > 1 && (ctx->opt_reduce_chunk & (ctx->opt_reduce_chunk - 1)) == 0) kb = ctx->opt_reduce_chunk;
+        while (kb > 2 && (size_t)kb * 4 > plan.nb) kb >>= 1;
+        slot.two_level_k = kb;
+        slot.bit_sliced = log2z(plan.nb / kb);
+    }
+    const size_t nout = slot.bit_sliced ? (size_t)(slot.bit_sliced + 2) * plan.nwin : (slot.two_level_k ? 2 : 1) * (size_t)plan.nwin;
+    const size_t tot_sm = slot.bit_sliced ? (plan.nb / slot.two_level_k) * plan.nwin : tot;      // chunk sums and moments
+    slot.red_a.ensure(tot_sm * psz);
+    slot.red_b.ensure(tot_sm * psz);
+    slot.red_c.ensure((slot.bit_sliced ? (size_t)(slot.bit_sliced + 1) * plan.nwin * (plan.nb / slot.two_level_k / 2) : tot) * psz);
     // the window sums are written straight into pinned host memory by the conversion kernel (device-visible, coherent): no
     // device-to-host copy is queued, so no runtime blit kernel appears inside a proof
     if (slot.host_bytes < nout * sizeof(XYZZ<FS>)) {
@@ -1077,7 +1136,21 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     };
     {
         ScopedKernelTimer kt(ctx, rname, (double)tb, aux);
-        if (!slot.two_level_k) {
+        if (slot.bit_sliced) {
+            const int kb = slot.two_level_k, bits = slot.bit_sliced;
+            const size_t ns = plan.nb / kb, half = ns / 2;
+            const int pw = (bits + 1) * plan.nwin;             // pseudo-windows: T_0 .. T_(bits-1), then the moments
+            hipLaunchKernelGGL(msm_chunk_local_kernel<F>, dim3((unsigned)((ns * plan.nwin + 63) / 64)), dim3(64), 0, aux, a.buckets, pa, pb, plan.nb, kb, plan.nwin);
+            hipLaunchKernelGGL(msm_bit_pairs_kernel<F>, dim3((unsigned)(((size_t)pw * half + 63) / 64)), dim3(64), 0, aux, pa, pb, pc, ns, bits, plan.nwin);
+            size_t live = half;
+            while (live > 1) {
+                const size_t h2 = (live + 1) / 2;
+                hipLaunchKernelGGL(msm_sum_step_kernel<F>, dim3((unsigned)((h2 * pw + 63) / 64)), dim3(64), 0, aux, pc, half, h2, live, pw);
+                live = h2;
+            }
+            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((pw + 63) / 64), dim3(64), 0, aux, pc, half, wsums_out, pw);
+            hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pa + (ns - 1), ns, wsums_out + pw, plan.nwin);
+        } else if (!slot.two_level_k) {
             weighted(a.buckets, plan.nb, kk, pa, pb, pc);
             hipLaunchKernelGGL(convert_wsums_kernel<F>, dim3((plan.nwin + 63) / 64), dim3(64), 0, aux, pc, nchunks, wsums_out, plan.nwin);
         } else {
@@ -1110,8 +1183,21 @@ static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
     (void)ctx;
     if (!slot.active) return XYZZ<FS>::inf();
     ZK_HIP(hipEventSynchronize(slot.red_done));
+    const auto host_t0 = std::chrono::steady_clock::now();
+    struct Lap { const std::chrono::steady_clock::time_point t0; MsmSlot &s; ~Lap() { s.collect_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } lap{host_t0, slot};
     const XYZZ<FS> *wsum = reinterpret_cast<const XYZZ<FS> *>(slot.wsums_host);
     auto window = [&](int w) {
+        if (slot.bit_sliced) {          // K (2^bits S_top + sum_t 2^t T_t) - M   (msm_bit_pairs_kernel)
+            const int bits = slot.bit_sliced;
+            XYZZ<FS> v = wsum[(bits + 1) * slot.nwin + w];
+            for (int t = bits - 1; t >= 0; t--) {
+                v = xyzz_dbl(v);
+                xyzz_add(v, wsum[t * slot.nwin + w]);
+            }
+            for (int k = slot.two_level_k; k > 1; k >>= 1) v = xyzz_dbl(v);
+            xyzz_add(v, xyzz_neg(wsum[bits * slot.nwin + w]));
+            return v;
+        }
         if (!slot.two_level_k) return wsum[w];
         XYZZ<FS> v = wsum[w];                       // W_w = K * P_w - M_w  (msm_chunk_local_kernel)
         for (int k = slot.two_level_k; k > 1; k >>= 1) v = xyzz_dbl(v);

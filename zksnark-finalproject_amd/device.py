@@ -290,8 +290,8 @@ class Device:
 
     # ---- instrumentation
     def last_timings(self):
-        buf = (C.c_float * 20)()
-        n = self.lib.zkg16_last_timings(self.ctx, buf, 20)
+        buf = (C.c_float * 22)()
+        n = self.lib.zkg16_last_timings(self.ctx, buf, 22)
         names = ["spmv", "witness_map", "msm_sort", "msm_h", "msm_l", "msm_a", "msm_b1", "msm_b2", "host_tail", "total_wall"]
         out = {names[i]: float(buf[i]) for i in range(min(n, 10))}
         if n >= 20:
@@ -307,6 +307,8 @@ class Device:
                 "Compute B in G2": {"accumulate": acc["B2"], "reduce": red["B2"]},
                 "Finish C": out["host_tail"],
             }
+        if n >= 22:     # host Horner over window sums: H's runs after the proof's last device event, the others under H's device work
+            out["host_horner_h"], out["host_horner_others"] = float(buf[20]), float(buf[21])
         return out
 
     def kernel_timing(self, enable=True):
