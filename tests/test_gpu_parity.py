@@ -442,7 +442,7 @@ def test_rank_roles_partial_finish_equals_single_proof(dev, oracle, ranks, h_ran
 def test_window_tables_same_proof(dev, oracle, cz, ch):
     """zkg16_pk_precompute: window tables 2^(c w) * base next to every base of the five queries, all digits of a scalar in ONE bucket
     set.  The proof must be the plain key's proof == the oracle's, bit for bit, for widths on both sides of the two- / three-pass
-    scatter (<= 20 / > 20 bucket bits), for one side only, and for the default (no table below 2^17 terms).  A shard cut out of a
+    scatter (<= 20 / > 20 bucket bits), for one side only, and for the default (16 bits below 2^16 terms).  A shard cut out of a
     key with tables sees level 0 = the plain query; a shard gets its own tables; a second precompute is refused."""
     from zksnark_finalproject_amd import Zkg16Error
     from zksnark_finalproject_amd.device import shard_plan
@@ -461,8 +461,10 @@ def test_window_tables_same_proof(dev, oracle, cz, ch):
     assert np.array_equal(plain[0], eproof) and np.array_equal(plain[1], einf)
     added = dev.pk_precompute(ph, cz, ch)
     n_h = (1 << 13) - 1
+    cz, ch = cz or 16, ch or 16                   # the default widths of queries below 2^16 terms
+    assert dev.pk_table_bits(ph) == (max(cz, 0), max(ch, 0))
     want = sum((254 // c) * n * sz for c, n, sz in ((cz, nv + 3, 3 * 112 + 224), (ch, n_h, 112)) if c > 0)
-    assert added == want                          # 0 for the default widths: both queries are far below 2^17 terms
+    assert added == want
     tabled = dev.prove_resident(ph, rh, wh, r, s)
     assert np.array_equal(tabled[0], plain[0]) and np.array_equal(tabled[1], plain[1])
     # zkg16_last_term_counts: the sorted term lists of that proof = mixed additions per MSM (what bench.py's `alu` figure divides by)
@@ -470,10 +472,9 @@ def test_window_tables_same_proof(dev, oracle, cz, ch):
     digits = lambda c, n: 254 // c + 1 if c > 0 else 254 // (13 if n >= (1 << 14) else max(4, n.bit_length() - 4)) + 1
     assert 0 < zc <= (nv + 3) * digits(cz, nv + 3) and 0 < hc <= n_h * digits(ch, n_h) and bc <= zc
     assert hc > n_h * (digits(ch, n_h) - 2)                  # h is dense: nearly every digit of every scalar is a term
-    if cz > 0 or ch > 0:
-        with pytest.raises(Zkg16Error) as e:
-            dev.pk_precompute(ph, cz, ch)
-        assert e.value.status == 1
+    with pytest.raises(Zkg16Error) as e:
+        dev.pk_precompute(ph, cz, ch)
+    assert e.value.status == 1
     # rank roles on top: shards of the tabled key, every other one with tables of its own
     plan, _ = shard_plan(3, nv, n_h, 0.0, 2)
     parts, pinf = [], []

@@ -1222,10 +1222,12 @@ int zkg16_shard_plan_tables(int n_ranks, size_t m_total, size_t n_h, double b_de
 // 20); 46x46 22.6 -> 19.65 at 17 (21.7 at 19); 128x128 181 -> 171.0 at 20 / 22 for z / h (172.0 at 20 / 20, 172.4 at 22 / 22,
 // 176.4 at 19 / 22).  Below 17 bits a bucket run spans more than the four lanes the short fix-up path handles (one resident round
 // of accumulation waves is 2^17 lanes) and everything goes through the long path: 46x46 at 16 bits 27.8 ms, at 15 bits 40 ms.
-// Queries under 3 * 2^17 terms get no table by default: a 237 k-term shard (46x46 over 4 ranks) measured 10.15 ms with a 17-bit
-// table against 9.33 ms without, the 444 k-term 32x32 key 12.05 against 13.4.
+// Every query gets a table by default: with the bit-sliced bucket reduction one bucket set of 2^15 / 2^16 buckets is reduced in ~20
+// dependent additions, so even small keys gain (profiles/table_sweep_r3.txt: 4x4 3.5 -> 2.45 ms and 8x8 3.9 -> 3.1 ms at 16 bits, 16x16
+// 5.6 -> 4.7 ms and the PrimeCircuit 5.9 -> 4.9 ms at 17; narrower tables lose: few buckets, each a long dependent chain).  Round 2
+// left queries under 3 * 2^17 terms plain because the reduction of 2^16 buckets then cost a G2 MSM 6 ms.
 static int default_table_bits(size_t n) {
-    if (n < ((size_t)3 << 17)) return 0;
+    if (n < ((size_t)1 << 16)) return 16;
     int best = 17;
     double best_cost = 0;
     for (int c : {17, 19, 20, 22}) {
