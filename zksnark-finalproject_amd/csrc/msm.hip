@@ -1306,9 +1306,9 @@ static void fixed_base_run(zkg16_ctx *ctx, FixedBaseCache &cache, const Affine<t
     // two levels (fixed_base_combine_kernel).  128x128 key: 51.5 M G1 points at 20 bits (1.5 GB table, 13 instead of 19 additions
     // each: 309 M additions saved for ~20 M spent on the table), 8.7 M G2 points at 18 bits.  Option "fixed_base_bits" forces a width.
     constexpr bool g2 = FieldTraits<FU>::g2;
-    int wbits = n >= ((size_t)1 << 21) ? 14 : n >= ((size_t)1 << 17) ? 12 : 8;
-    if (!g2) { if (n >= ((size_t)1 << 25)) wbits = 20; else if (n >= ((size_t)1 << 23)) wbits = 18; else if (n >= ((size_t)1 << 22)) wbits = 16; }
-    else { if (n >= ((size_t)1 << 23)) wbits = 18; else if (n >= ((size_t)1 << 22)) wbits = 16; }
+    int wbits = n >= ((size_t)1 << 17) ? 12 : 8;
+    if (!g2) { if (n >= ((size_t)1 << 25)) wbits = 20; else if (n >= ((size_t)1 << 24)) wbits = 18; else if (n >= ((size_t)1 << 21)) wbits = 16; }
+    else { if (n >= ((size_t)1 << 23)) wbits = 18; else if (n >= ((size_t)1 << 20)) wbits = 16; }      // (64x64: setup 59.6 -> 54.3 ms with 16 / 16 instead of 18 / 12)
     if (ctx->opt_fixed_base_bits) wbits = ctx->opt_fixed_base_bits;
     const bool two_level = wbits >= 16;             // even widths only (checked by the option)
     const int nwin = (256 + wbits - 1) / wbits;
