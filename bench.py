@@ -650,9 +650,18 @@ def main():
             if peak is None:
                 peak = profile_lookup(["alu", "madd_g1_bare_gadd_per_s"])
             mad_bound = profile_lookup(["alu", "mad_bound_gadd_per_s"])
+            try:
+                res_g1, res_g2 = dev.acc_resident_waves()
+            except Exception:      # noqa: BLE001
+                res_g1 = res_g2 = None
+            peak_res = by_waves.get(str(res_g1)) if res_g1 else None
             out["alu"] = {"kernel": "msm_accumulate_g1", "achieved": gadd, "peak": peak, "unit": "G mixed additions/s",
                           "frac": (gadd / peak) if peak else None,
                           "waves_per_simd": {"z": acc_waves[0], "b": acc_waves[1], "h": acc_waves[2]},
+                          # the kernel's registers (255) let a SIMD HOLD two waves; a grid sized for four runs them as two rounds.  `frac`
+                          # stays against the four-wave row (the stricter reading); the row of the resident occupancy is beside it
+                          "resident_waves_per_simd": {"g1": res_g1, "g2": res_g2},
+                          "peak_at_resident_waves": peak_res, "frac_at_resident_waves": (gadd / peak_res) if peak_res else None,
                           "mad_bound": mad_bound, "frac_of_mad_bound": (gadd / mad_bound) if mad_bound else None,
                           "additions_per_launch": exact, "term_lists": {"z": zc, "b": bc, "h": hc}, "additions_per_launch_estimate": est,
                           "note": "additions = lengths of the sorted term lists of the last proof, read back from the device "

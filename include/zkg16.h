@@ -307,6 +307,9 @@ ZKG16_API int zkg16_last_timings(zkg16_ctx *ctx, float *ms, int cap);
 ZKG16_API int zkg16_last_term_counts(zkg16_ctx *ctx, uint64_t counts[3]);
 /* G1 accumulation waves per SIMD (2 or 4) the last proof's term lists ran at: [0] z list, [1] B list, [2] h list; 0 = not built. */
 ZKG16_API int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]);
+/* Waves of the bucket-accumulation kernels one SIMD holds at once (their register use decides): [0] G1, [1] G2.  The grid of an
+ * accumulation may be sized for more waves per SIMD than that (zkg16_last_acc_waves): the extra ones run as a second round. */
+ZKG16_API int zkg16_acc_resident_waves(zkg16_ctx *ctx, int waves[2]);
 /* The lanes of the most recent proofs: rows of (lane, start ms, end ms) on the host's steady clock, oldest first; returns the number of
  * rows written (<= cap_rows).  Two rows with different lanes and intersecting intervals = two proofs in flight at once. */
 ZKG16_API int zkg16_lane_log(zkg16_ctx *ctx, double *rows, int cap_rows);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "zkg16_last_term_counts": (C.c_int, [ctxp, C.POINTER(C.c_uint64)]),
     "zkg16_lane_log": (C.c_int, [ctxp, C.POINTER(C.c_double), C.c_int]),
     "zkg16_last_acc_waves": (C.c_int, [ctxp, C.POINTER(C.c_int)]),
+    "zkg16_acc_resident_waves": (C.c_int, [ctxp, C.POINTER(C.c_int)]),
     "zkg16_pk_table_bits": (C.c_int, [ctxp, H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "zkg16_shard_plan": (C.c_int, [C.c_int, sz, sz, C.c_double, C.c_int, vp, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_shard_plan_tables": (C.c_int, [C.c_int, sz, sz, C.c_double, C.c_int, vp, C.c_int, u64p, u8p, C.POINTER(C.c_int)]),

@@ -1779,6 +1779,15 @@ int zkg16_last_acc_waves(zkg16_ctx *ctx, int waves[3]) {
     return ZKG16_OK;
 }
 
+// waves of the accumulation kernels (as launched with the ctx's current options) that fit one SIMD at once: [0] G1, [1] G2
+int zkg16_acc_resident_waves(zkg16_ctx *ctx, int waves[2]) {
+    if (!waves) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    waves[0] = msm_acc_resident_waves(ctx, false);
+    waves[1] = msm_acc_resident_waves(ctx, true);
+    ZK_API_END(ctx)
+}
+
 // the lanes (host intervals, steady-clock ms) of the most recent proofs on this ctx: rows of (lane, start, end); returns the
 // number of rows written.  Two proofs whose intervals intersect on different lanes ran at the same time.
 int zkg16_lane_log(zkg16_ctx *ctx, double *rows, int cap_rows) {

@@ -359,6 +359,7 @@ void fr_powers_run(zkg16_ctx *ctx, Fr *out, const Fr &base, const Fr &scale, siz
 // the two halves of an enqueue, for callers that interleave other launches between them (prove_device)
 // round: -1 = the whole MSM in one accumulation (default); k >= 0 = round k of an MSM whose terms arrive in several rounds
 // (same plan geometry every round): the rounds' bucket arrays are summed and ONE reduction follows (msm_*_enqueue_reduce)
+int msm_acc_resident_waves(zkg16_ctx *ctx, bool g2);
 void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot, int round = -1);
 void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot, int round = -1);
 void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot);

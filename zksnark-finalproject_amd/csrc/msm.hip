@@ -1214,6 +1214,24 @@ static XYZZ<FS> msm_collect(zkg16_ctx *ctx, MsmSlot &slot) {
     return total;
 }
 
+// Waves of the shipped accumulation kernels one SIMD can hold at once (registers: 255 for G1, 478 for G2 in this build): what the
+// bare-loop comparison of bench.py has to be read against, beside the waves per SIMD the grid is sized for (zkg16_last_acc_waves).
+int msm_acc_resident_waves(zkg16_ctx *ctx, bool g2) {
+    int blocks = 0;
+    const bool pipe = (ctx->opt_acc_pipeline >> (g2 ? 1 : 0)) & 1;
+    hipError_t e;
+    if (g2) {
+        if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, msm_accumulate_kernel<Fq2U, true>, 64, 0);
+        else if (ctx->opt_g2_lazy) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, msm_accumulate_kernel<Fq2U, false, true>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, msm_accumulate_kernel<Fq2U, false>, 64, 0);
+    } else {
+        if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, msm_accumulate_kernel<FqU, true>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, msm_accumulate_kernel<FqU, false>, 64, 0);
+    }
+    ZK_HIP(e);
+    return blocks / 4;      // one-wave blocks per CU -> waves per SIMD
+}
+
 void msm_g1_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G1AffineU *bases, MsmSlot &slot, int round) { msm_enqueue_acc<FqU>(ctx, ws, plan, bases, slot, round); }
 void msm_g2_enqueue_acc(zkg16_ctx *ctx, MsmWorkspace &ws, const MsmPlan &plan, const G2AffineU *bases, MsmSlot &slot, int round) { msm_enqueue_acc<Fq2U>(ctx, ws, plan, bases, slot, round); }
 void msm_g1_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) { msm_enqueue_reduce<FqU>(ctx, slot); }

@@ -96,6 +96,12 @@ class Device:
         self._check(self.lib.zkg16_last_acc_waves(self.ctx, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def acc_resident_waves(self):
+        """-> (G1, G2) waves of the accumulation kernels one SIMD holds at once (zkg16_acc_resident_waves)."""
+        out = (C.c_int * 2)()
+        self._check(self.lib.zkg16_acc_resident_waves(self.ctx, out))
+        return int(out[0]), int(out[1])
+
     def pk_table_bits(self, pk_h):
         """-> (window bits of the z-side tables, of the h-side table); 0 = none (zkg16_pk_table_bits)."""
         bz, bh = C.c_int(0), C.c_int(0)
