@@ -323,7 +323,8 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
 /* Tuning / A-B switches; none of them changes a result (tests/test_gpu_parity.py toggles every one and compares proofs).
  *   "window_bits"    MSM window bits c for every plan (0 = by size: 13 / 15 / 16 / 17; <= 20)      "window_bits_h"  the H MSM's plan only
  *   "reduce_chunk"   buckets per lane in the bucket reduction (0 = 8)                   "reduce_mode"    1 = work-efficient two-level form,
- *                    2 = that form except for the proof's last MSM, 4 = classic everywhere, 0 = default (2 from 16-bit windows on)
+ *                    2 = that form except for the proof's last MSM, 4 = classic everywhere, 5 = bit-sliced wherever it applies,
+ *                    6 = the default without the bit-sliced form, 0 = default (bit-sliced for bucket sets up to 2^19, else 2 from 16-bit windows on)
  *   "sort_mode"      0 = hand-written wave-ballot bucket scatter (default), 1 = rocPRIM radix sort
  *   "acc_pipeline"   bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product; 4 = off, 0 = default (both)
  *   "wm_concurrent"  0 = witness map in order on the main stream (default: own stream)  "fixup_aux"      1 = fix-ups on the reduction stream
