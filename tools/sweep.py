@@ -3,7 +3,7 @@ then verify; bench/fibo.py:26-60: Fibonacci rounds 0..186 with a = 0, b = 1), th
 HTTP.  Records the reference's fields: num_constraints, setup_time, proving_time, verifying_time (seconds).
 bench/prime.py:17-70: random x of 2, 4, .. 64 bits, i = 32 candidates, retried until a prime is found, prove then verify
 with the returned pvk.
-    python tools/sweep.py matrix [max_power=6]   |   python tools/sweep.py fib [step=31]   |   python tools/sweep.py prime [per_size=2]"""
+    python tools/sweep.py matrix [max_power=6] [warm]   |   python tools/sweep.py fib [step=31]   |   python tools/sweep.py prime [per_size=2]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,9 @@ if kind == "matrix":
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     print("size,num_constraints,request_time,setup_time,proving_time,verifying_time,valid,decode_time")
     handlers.prove_matrix(dev, 2, np.ones((2, 2), dtype=np.uint64), np.ones((2, 2), dtype=np.uint64))      # warm-up (tables, streams)
+    if len(sys.argv) > 3 and sys.argv[3] == "warm":      # a server that has served the largest size before: its buffers exist (on some
+        nw = 1 << top                                    # boxes the first multi-GB hipMalloc calls of a process cost 1-3 s, once)
+        handlers.prove_matrix(dev, nw, np.ones((nw, nw), dtype=np.uint64), np.ones((nw, nw), dtype=np.uint64))
     for k in range(1, top + 1):
         n = 1 << k
         ones = np.ones((n, n), dtype=np.uint64)

@@ -292,7 +292,13 @@ void *dev_acquire(size_t bytes, size_t *got) {
         }
     }
     void *p = nullptr;
+    const bool trace = getenv("ZKG16_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, bytes);
+    if (trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 1.0) fprintf(stderr, "dev_acquire: hipMalloc of %.1f MB took %.2f ms\n", bytes / 1048576.0, ms);
+    }
     if (e != hipSuccess) {                      // out of memory with blocks parked in the cache: give them back and retry once
         (void)hipGetLastError();
         dev_cache_flush();
@@ -304,7 +310,13 @@ void *dev_acquire(size_t bytes, size_t *got) {
 void dev_release(void *p, size_t bytes) noexcept {
     DevCache &c = dev_cache();
     if (bytes >= DevCache::MIN_CACHED) {
+        const bool trace = getenv("ZKG16_TRACE_ALLOC") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         (void)hipDeviceSynchronize();           // what hipFree would have done
+        if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 1.0) fprintf(stderr, "dev_release: sync before caching %.1f MB took %.2f ms\n", bytes / 1048576.0, ms);
+        }
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(c.mu);
@@ -314,7 +326,13 @@ void dev_release(void *p, size_t bytes) noexcept {
             return;
         }
     }
+    const bool trace = getenv("ZKG16_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     (void)hipFree(p);
+    if (trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 1.0) fprintf(stderr, "dev_release: hipFree of %.1f MB took %.2f ms\n", bytes / 1048576.0, ms);
+    }
 }
 void dev_cache_flush() noexcept {
     DevCache &c = dev_cache();
