@@ -71,6 +71,7 @@ struct Circuit {
         std::vector<Term> t;
         size_t size() const { return ptr.size() - 1; }
         void push(const std::vector<Term> &row) { t.insert(t.end(), row.begin(), row.end()); ptr.push_back(t.size()); }
+        void push(const Term *row, size_t n) { t.insert(t.end(), row, row + n); ptr.push_back(t.size()); }
     } rows[3];
 
     // A circuit may be built as several segments (zkg16_circuit): a segment's own witnesses are numbered from wit_base in
@@ -102,6 +103,14 @@ struct Circuit {
         r.val = v;
         r.is_const = false;
         return r;
+    }
+    VarId new_witness_id(const Fr &v) {      // new_witness without the one-term Lc (a heap allocation per call)
+        witness.push_back(v);
+        return WIT | (VarId)(next_wit() - 1);
+    }
+    VarId new_input_id(const Fr &v) {
+        instance.push_back(v);
+        return (VarId)(instance.size() - 1);
     }
     static Lc add(const Lc &a, const Lc &b) {
         Lc r;
