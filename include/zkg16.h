@@ -230,6 +230,12 @@ ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, s
 ZKG16_API int zkg16_circuit_is_satisfied(const zkg16_circuit *c);
 ZKG16_API int zkg16_circuit_export(const zkg16_circuit *c, uint64_t *const row_ptr[3], uint32_t *const col[3], uint64_t *const coeff[3],
                          uint64_t *full_assignment /* (num_instance + num_witness) x 4 */);
+/* The public inputs (instance assignment without the leading one): (num_instance - 1) x 4 limbs; cap = room in elements. */
+ZKG16_API int zkg16_circuit_public_inputs(const zkg16_circuit *c, uint64_t *out, size_t cap);
+/* Load a synthesized circuit straight onto the device: *r1cs_handle as from zkg16_r1cs_load and *witness_handle as from
+ * zkg16_witness_load of zkg16_circuit_export's arrays (same bytes on the device), staged through pinned memory the ctx keeps — the
+ * request path of the handlers whose circuits are re-synthesized per request (PrimeCircuit, Fibonacci). */
+ZKG16_API int zkg16_circuit_load(zkg16_ctx *ctx, const zkg16_circuit *c, uint64_t *r1cs_handle, uint64_t *witness_handle);
 /* ---- the MatrixCircuit's assignment built ON THE DEVICE (scope row f-4 "on GPU"; csrc/witness.hip).  The reference re-synthesises
  * the circuit inside its timed `Groth16::prove` (matrix_proof.rs:138-145, constraints.rs:78-128): per request only the
  * assignment changes, 75 % of which are the S-box products of 3 ceil(n^2/2) Poseidon permutations (hashing_utils.rs:737-802).

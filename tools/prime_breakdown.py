@@ -31,3 +31,11 @@ for x in (58405, 93, 13, 1234567):
     e2 = wire.encode_pvk(vk); lap("encode_pvk")
     e3 = wire.encode_vk(vk); lap("encode_vk")
     print(x, "total %.1f ms: " % sum(T.values()) + ", ".join("%s %.1f" % kv for kv in T.items()), flush=True)
+for x in (58405, 93, 13, 1234567):
+    t0 = time.perf_counter()
+    res = handlers.prove_prime(dev, x, 32)
+    t1 = time.perf_counter()
+    v = handlers.verify_prime(res["pvk"], x, res["j"], res["proof"])
+    t2 = time.perf_counter()
+    print("handler: prove_prime %.1f ms (setup %.1f, proof %.1f), verify_prime %.1f ms (verifying %.2f, decode %.1f) valid %s" % ((t1 - t0) * 1e3, res["setup_time"] * 1e3,
+          res["proving_time"] * 1e3, (t2 - t1) * 1e3, v["verifying_time"] * 1e3, v["decode_time"] * 1e3, v["valid"]), flush=True)

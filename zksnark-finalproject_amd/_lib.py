@@ -69,6 +69,8 @@ SIGNATURES = {
     "zkg16_circuit_dims": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
     "zkg16_circuit_is_satisfied": (C.c_int, [vp]),
     "zkg16_circuit_export": (C.c_int, [vp, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3), u64p]),
+    "zkg16_circuit_public_inputs": (C.c_int, [vp, u64p, sz]),
+    "zkg16_circuit_load": (C.c_int, [ctxp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkg16_poseidon_hash": (C.c_int, [u64p, sz, u64p]),
     "zkg16_r1cs_matrix": (C.c_int, [ctxp, sz, C.POINTER(H)]),
     "zkg16_r1cs_read": (C.c_int, [ctxp, H, vp, vp, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),

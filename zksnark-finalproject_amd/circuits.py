@@ -35,6 +35,52 @@ class SynthesizedCircuit:
         lib.zkg16_circuit_free(handle)
 
 
+class CircuitHandle:
+    """A synthesized circuit that stays inside the library: its dimensions and public inputs only.  Device.circuit_load(self) puts
+    its matrices and assignment on the device without exporting them (the request path of circuits that are re-synthesized per
+    request); close() (or garbage collection) frees it."""
+
+    def __init__(self, handle):
+        lib = _lib.load()
+        self.handle = handle
+        ni, nw, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        nnz = (C.c_size_t * 3)()
+        lib.zkg16_circuit_dims(handle, C.byref(ni), C.byref(nw), C.byref(nc), C.byref(nnz))
+        self.num_instance, self.num_witness, self.num_constraints = ni.value, nw.value, nc.value
+        self.num_vars = ni.value + nw.value
+        pub = np.zeros((max(ni.value - 1, 0), 4), dtype=np.uint64)
+        if ni.value > 1:
+            rc = lib.zkg16_circuit_public_inputs(handle, pub.reshape(-1), ni.value - 1)
+            if rc:
+                raise Zkg16Error(rc, "zkg16_circuit_public_inputs")
+        self.public_inputs = pub
+        self.domain = 1 << max(self.num_constraints + self.num_instance - 1, 0).bit_length()
+        self.satisfied = None
+        self.z = self.r1cs = None
+
+    def close(self):
+        if self.handle is not None:
+            _lib.load().zkg16_circuit_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def prime_circuit_handle(x, j):
+    """PrimeCircuit of candidate j as a CircuitHandle (nothing exported to Python)."""
+    h = C.c_void_p()
+    rc = _lib.load().zkg16_circuit_prime(x, j, C.byref(h))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_prime")
+    c = CircuitHandle(h)
+    c.j = j
+    return c
+
+
 def matrix_circuit(a, b):
     """MatrixCircuit for u64 matrices a, b (n x n lists/arrays); public inputs = Poseidon hashes of A, B, C = A*B."""
     a = np.ascontiguousarray(a, dtype=np.uint64)

@@ -103,6 +103,9 @@ void teardown(zkg16_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->wm_stream);
     if (ctx->extra_host) (void)hipHostFree(ctx->extra_host);
+    if (ctx->circuit_stage) (void)hipHostFree(ctx->circuit_stage);
+    ctx->circuit_stage = nullptr;
+    ctx->circuit_stage_bytes = 0;
     for (int i = 0; i < 2; i++) {
         if (ctx->stage_host[i]) (void)hipHostFree(ctx->stage_host[i]);
         if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
@@ -1312,6 +1315,52 @@ int zkg16_r1cs_load(zkg16_ctx *ctx,
     const uint64_t *cf[3] = {a_coeff, b_coeff, c_coeff};
     int rc = load_r1cs(ctx, rp, col, cf, num_instance, num_constraints, num_variables, r1cs_handle);
     if (rc) return rc;
+    ZK_API_END(ctx)
+}
+
+// A synthesized circuit (zkg16_circuit_*) loaded straight onto the device: the handles zkg16_r1cs_load / zkg16_witness_load would
+// return for zkg16_circuit_export's arrays, without those arrays crossing the ABI.  The arrays are written into pinned staging memory
+// the ctx keeps (grown on demand): a caller that exported into fresh buffers per request paid for 65 MB of allocation, page faults
+// and unmapping around every PrimeCircuit request — and the unmapping slowed the NEXT synthesis from 18 to 45-60 ms on the GPU box.
+int zkg16_circuit_load(zkg16_ctx *ctx, const zkg16_circuit *c, uint64_t *r1cs_handle, uint64_t *witness_handle) {
+    if (!c || !r1cs_handle || !witness_handle) return ZKG16_ERR_BAD_ARG;
+    size_t ni = 0, nw = 0, nc = 0, nnz[3] = {0, 0, 0};
+    if (zkg16_circuit_dims(c, &ni, &nw, &nc, nnz) != ZKG16_OK) return ZKG16_ERR_BAD_ARG;
+    ZK_API_BEGIN(ctx)
+    zkg16_ctx *root = ctx->root ? ctx->root : ctx;
+    // layout of the staging block: 3 row-pointer arrays, 3 column arrays, 3 coefficient arrays, the assignment; 64-byte aligned
+    size_t off[10], total = 0;
+    auto place = [&](int i, size_t bytes) { off[i] = total; total += (bytes + 63) & ~(size_t)63; };
+    for (int m = 0; m < 3; m++) place(m, (nc + 1) * sizeof(uint64_t));
+    for (int m = 0; m < 3; m++) place(3 + m, (nnz[m] ? nnz[m] : 1) * sizeof(uint32_t));
+    for (int m = 0; m < 3; m++) place(6 + m, (nnz[m] ? nnz[m] : 1) * sizeof(Fr));
+    place(9, (ni + nw) * sizeof(Fr));
+    if (root->circuit_stage_bytes < total) {
+        if (root->circuit_stage) (void)hipHostFree(root->circuit_stage);
+        root->circuit_stage = nullptr;
+        root->circuit_stage_bytes = 0;
+        ZK_HIP(hipHostMalloc(&root->circuit_stage, total + total / 8, hipHostMallocDefault));
+        root->circuit_stage_bytes = total + total / 8;
+    }
+    uint8_t *base = static_cast<uint8_t *>(root->circuit_stage);
+    uint64_t *rp[3], *cf[3], *z = reinterpret_cast<uint64_t *>(base + off[9]);
+    uint32_t *col[3];
+    for (int m = 0; m < 3; m++) {
+        rp[m] = reinterpret_cast<uint64_t *>(base + off[m]);
+        col[m] = reinterpret_cast<uint32_t *>(base + off[3 + m]);
+        cf[m] = reinterpret_cast<uint64_t *>(base + off[6 + m]);
+    }
+    if (zkg16_circuit_export(c, rp, col, cf, z) != ZKG16_OK) return ZKG16_ERR_BAD_ARG;
+    const uint64_t *crp[3] = {rp[0], rp[1], rp[2]}, *ccf[3] = {cf[0], cf[1], cf[2]};
+    const uint32_t *ccol[3] = {col[0], col[1], col[2]};
+    auto w = std::make_unique<WitnessDev>();
+    w->n = ni + nw;
+    w->z.alloc(w->n * sizeof(Fr));
+    ZK_HIP(hipMemcpyAsync(w->z.p, z, w->n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    const int rc = load_r1cs(ctx, crp, ccol, ccf, ni, nc, ni + nw, r1cs_handle);      // synchronises the stream: the staging block is free again
+    if (rc) return rc;
+    *witness_handle = ctx->next_handle++;
+    ctx->wits.put(*witness_handle, std::move(w));
     ZK_API_END(ctx)
 }
 

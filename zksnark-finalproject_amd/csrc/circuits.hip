@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <thread>
@@ -499,6 +500,7 @@ static Lc poseidon_hash_chunked(std::vector<SpongeChunk> &ch, const std::vector<
 struct zkg16_circuit {
     // segments in row order; segs[0] holds the instance variables.  Witness values: each segment's own, at its wit_base.
     std::vector<std::unique_ptr<Circuit>> segs;
+    bool pooled_storage = false;       // the PrimeCircuit's one segment: its vectors go back to prime_store() when it is freed
     Circuit &head() { return *segs[0]; }
     const Circuit &head() const { return *segs[0]; }
     Circuit &add_segment(size_t wit_base) {
@@ -837,6 +839,23 @@ int zkg16_prime_candidate(uint64_t x, uint64_t j, uint8_t digest_out[32], uint32
 }
 // PrimeCircuit::new(...) for the candidate at index j, as prove_prime builds it for the j it found and verify_prime
 // rebuilds it to recover the public inputs (prime_snark.rs:98-105, 170-193).  Instance: 1, x, the 256 digest bits.
+// The PrimeCircuit's storage (75 MB of rows and witness values, the same size for every request) kept between requests: fresh
+// vectors of that size come from mmap and every request paid ~18 k page faults — 20 to 45 ms on the GPU box's host, more than the
+// 14 ms the synthesis itself takes.  One set; a second concurrent build simply allocates.
+namespace {
+struct PrimeStore {
+    std::mutex mu;
+    bool full = false;
+    std::vector<Fr> witness;
+    std::vector<Term> t[3];
+    std::vector<uint64_t> ptr[3];
+};
+PrimeStore &prime_store() {
+    static PrimeStore s;
+    return s;
+}
+}  // namespace
+
 int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
     if (!out) return ZKG16_ERR_BAD_ARG;
     *out = nullptr;
@@ -846,7 +865,24 @@ int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
         if (cand.base[k] == 0) return ZKG16_ERR_UNSUPPORTED;  // base.inverse().unwrap() panics upstream
     try {
         std::unique_ptr<zkg16_circuit> c(new zkg16_circuit());
-        build_prime_circuit(c->add_segment(0), x, j, cand);
+        Circuit &seg = c->add_segment(0);
+        c->pooled_storage = true;
+        {
+            PrimeStore &st = prime_store();
+            std::lock_guard<std::mutex> lk(st.mu);
+            if (st.full) {
+                st.full = false;
+                seg.witness.swap(st.witness);
+                for (int m = 0; m < 3; m++) {
+                    seg.rows[m].t.swap(st.t[m]);
+                    seg.rows[m].ptr.swap(st.ptr[m]);
+                    seg.rows[m].t.clear();
+                    seg.rows[m].ptr.assign(1, 0);
+                }
+                seg.witness.clear();
+            }
+        }
+        build_prime_circuit(seg, x, j, cand);
         *out = c.release();
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
@@ -1142,6 +1178,19 @@ int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b,
 
 void zkg16_circuit_free(zkg16_circuit *c) {
     if (!c) return;
+    if (c->pooled_storage && c->segs.size() == 1) {
+        PrimeStore &st = prime_store();
+        std::lock_guard<std::mutex> lk(st.mu);
+        if (!st.full) {
+            Circuit &seg = *c->segs[0];
+            st.witness.swap(seg.witness);
+            for (int m = 0; m < 3; m++) {
+                st.t[m].swap(seg.rows[m].t);
+                st.ptr[m].swap(seg.rows[m].ptr);
+            }
+            st.full = true;
+        }
+    }
     size_t terms = 0;
     for (const auto &sg : c->segs) terms += sg->rows[0].t.size() + sg->rows[1].t.size() + sg->rows[2].t.size();
     if (terms < (1u << 16)) {
@@ -1167,6 +1216,15 @@ int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num
     if (num_constraints) *num_constraints = rows;
     if (nnz)
         for (int m = 0; m < 3; m++) nnz[m] = k[m];
+    return ZKG16_OK;
+}
+
+// the instance assignment without the leading one (= the public inputs a verifier is given): (num_instance - 1) x 4 limbs
+int zkg16_circuit_public_inputs(const zkg16_circuit *c, uint64_t *out, size_t cap) {
+    if (!c || c->segs.empty() || !out) return ZKG16_ERR_BAD_ARG;
+    const std::vector<Fr> &inst = c->head().instance;
+    if (cap + 1 < inst.size()) return ZKG16_ERR_BAD_ARG;
+    if (inst.size() > 1) memcpy(out, inst.data() + 1, (inst.size() - 1) * sizeof(Fr));
     return ZKG16_OK;
 }
 

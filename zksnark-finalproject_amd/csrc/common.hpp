@@ -281,6 +281,8 @@ struct zkg16_ctx {
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort
     int opt_acc_pipeline = 0;                         // bit 0 / 1: G1 / G2 accumulation gathers the next base behind the last (inlined) product (default: neither)
+    void *circuit_stage = nullptr;                    // pinned staging block of zkg16_circuit_load (root ctx; grown on demand)
+    size_t circuit_stage_bytes = 0;
     int opt_collect_threads = -1;                     // -1: the z-side MSMs' window sums are combined on their own host threads when the key is plain; 1 always; 0 never
     int opt_fixed_base_bits = 0;                      // setup's fixed-base window width (0 = by batch size; even widths >= 16 are built in two levels)
     int opt_g2_lazy = 1;                              // G2 accumulation: Fq2 products with one reduction per component, operands parked in LDS (ffu.cuh: fq2u_mul_lazy)

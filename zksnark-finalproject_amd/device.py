@@ -96,6 +96,13 @@ class Device:
         self._check(self.lib.zkg16_last_acc_waves(self.ctx, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def circuit_load(self, circuit):
+        """circuit: a circuits.CircuitHandle (a synthesized circuit still held by the library) -> (r1cs_handle, witness_handle), loaded
+        without exporting its arrays to Python (zkg16_circuit_load)."""
+        rh, wh = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.zkg16_circuit_load(self.ctx, circuit.handle, C.byref(rh), C.byref(wh)))
+        return rh.value, wh.value
+
     def acc_resident_waves(self):
         """-> (G1, G2) waves of the accumulation kernels one SIMD holds at once (zkg16_acc_resident_waves)."""
         out = (C.c_int * 2)()

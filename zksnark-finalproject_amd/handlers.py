@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import wire
-from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_search
+from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_circuit_handle, prime_search
 from .workloads import R_MOD, g1_generator, g2_generator
 
 
@@ -66,12 +66,18 @@ def _setup_and_prove(dev, circ, rng, keep_key=False):
     g1 = scalar_mul("g1", g1_generator(), k)[0]
     g2 = scalar_mul("g2", g2_generator(), k)[0]
     cached = getattr(circ, "rh", None) is not None
-    rh = circ.rh if cached else dev.r1cs_load(circ.r1cs, circ.num_vars)
+    direct = getattr(circ, "handle", None) is not None          # a CircuitHandle: matrices and assignment go to the device unexported
+    wh_direct = None
+    if direct:
+        rh, wh_direct = dev.circuit_load(circ)
+        circ.close()
+    else:
+        rh = circ.rh if cached else dev.r1cs_load(circ.r1cs, circ.num_vars)
     # cached shape: the assignment needs neither the key nor (for its host half, the three Poseidon chains) the device, so it is
     # started now and runs beside the setup's kernels (zkg16_witness_matrix takes the ctx only for its ~1 ms of kernels): at 128x128
     # the 61 ms of chains disappear under the 0.2 s setup and the proof is the plain resident one (0.17 s instead of 0.195 s streamed)
     early = None
-    if circ.z is None and not keep_key:
+    if circ.z is None and not keep_key and not direct:
         import threading
         early = {}
 
@@ -108,14 +114,14 @@ def _setup_and_prove(dev, circ, rng, keep_key=False):
         proof, inf = dev.prove_resident(ph, rh, wh, r, s)
         proving_time = time.perf_counter() - t0
         circ.public_inputs = pub
-    elif circ.z is None:                # cached shape: the assignment is produced on the device while the proof runs
+    elif circ.z is None and not direct:  # cached shape: the assignment is produced on the device while the proof runs
         t0 = time.perf_counter()
         proof, inf, pub, _ = dev.prove_matrix(ph, rh, circ.matrices[0], circ.matrices[1], r, s)
         proving_time = time.perf_counter() - t0
         circ.public_inputs = pub
         wh = None
     else:
-        wh = dev.witness_load(circ.z)
+        wh = wh_direct if direct else dev.witness_load(circ.z)
         t0 = time.perf_counter()
         proof, inf = dev.prove_resident(ph, rh, wh, r, s)
         proving_time = time.perf_counter() - t0
@@ -163,7 +169,10 @@ def prove_prime(dev, x, i, seed=7, keep_key=False, check_satisfied=False):
     found = prime_search(x, i)
     if not found["found"]:
         return dict(proof="", j=0, num_constraints=0, num_variables=0, setup_time=0.0, proving_time=0.0, found_prime=False, prime_num="", vk="")
-    circ = prime_circuit(x, found["j"], search=False, check_satisfied=check_satisfied)
+    if keep_key or check_satisfied:     # tests want the arrays (and the satisfaction check) on the host
+        circ = prime_circuit(x, found["j"], search=False, check_satisfied=check_satisfied)
+    else:
+        circ = prime_circuit_handle(x, found["j"])
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), j=found["j"], num_constraints=circ.num_constraints,
                 num_variables=circ.num_vars, setup_time=out["setup_time"], proving_time=out["proving_time"], found_prime=True,
@@ -174,8 +183,10 @@ def prove_prime(dev, x, i, seed=7, keep_key=False, check_satisfied=False):
 def verify_prime(vk, x, j, proof_b64):
     """Mirror of verify_prime (prime_snark.rs:165-206): the verifier re-synthesizes PrimeCircuit for (x, j) to recover the
     public inputs (x and the 256 digest bits), then checks the proof."""
-    circ = prime_circuit(x, j, search=False, check_satisfied=False)
-    return verify_proof(vk, circ.public_inputs, proof_b64)
+    circ = prime_circuit_handle(x, j)
+    pub = circ.public_inputs
+    circ.close()
+    return verify_proof(vk, pub, proof_b64)
 
 
 def verify_proof(vk, public_inputs_mont, proof_b64):
