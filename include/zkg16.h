@@ -195,6 +195,11 @@ ZKG16_API int zkg16_pvk_prepare(const uint64_t alpha_g1[12], const uint64_t beta
 ZKG16_API int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_instance, const uint64_t *public_inputs, const uint64_t alpha_beta[72],
                           const uint64_t *gamma_neg_coeffs, const uint64_t *delta_neg_coeffs, size_t n_coeffs,
                           const uint64_t proof[48], const uint8_t inf[3], int *ok);
+/* n compressed G1 points (48 bytes each, the ark-serialize / zcash encoding the reference's keys and proofs travel in) -> affine
+ * Montgomery limbs (n x 12) + infinity flags, strict as G1Affine::deserialize_compressed (+ the subgroup check when validate).
+ * status (nullable, n ints): 0 ok, 1 not compressed, 2 non-canonical infinity, 3 x not reduced, 4 not on the curve, 5 not in the
+ * subgroup; returns ZKG16_ERR_BAD_ARG if any point failed. */
+ZKG16_API int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status);
 ZKG16_API int zkg16_point_check(int group, const uint64_t *point, int *ok);
 
 /* prod_i e(P_i, Q_i) == 1 ?  Host-only (no ctx, no GPU).  g1: n x 12 limbs, g2: n x 24 limbs, flag bytes nullable.

@@ -122,6 +122,52 @@ def test_decompression_rejects_what_arkworks_rejects():
     assert verify(vk, np.zeros((0, 4), np.uint64), proof, np.zeros(3, np.uint8)) is False
 
 
+def test_native_g1_decompression_equals_python_rules():
+    """zkg16_g1_decompress (what verifying keys are decoded with) against wire.g1_decompress, the pure-Python statement of the same
+    rules: random subgroup points with both signs, infinity, and every refusal — not compressed, dirty infinity, x >= q, x without a
+    point, a curve point outside the subgroup (refused only when validating)."""
+    import pytest
+    from zksnark_finalproject_amd import wire
+    from zksnark_finalproject_amd.device import point_check
+    rng = random.Random(77)
+    encs = [wire.g1_compress(py_g1(P.g1_mul(rng.randrange(1, P.R_MOD)))[0], 0) for _ in range(40)] + [bytes([0xC0]) + bytes(47)]
+    got, ginf = wire.g1_decompress_many(b"".join(encs), len(encs))
+    for i, e in enumerate(encs):
+        want, winf = wire.g1_decompress(e)
+        assert winf == ginf[i] and np.array_equal(got[i], want), i
+    assert sum(1 for e in encs if e[0] & 0x20) not in (0, len(encs))          # both signs occurred
+    good = encs[0]
+    x = int.from_bytes(bytes([good[0] & 0x1F]) + good[1:], "big")
+    no_point = None
+    while no_point is None:
+        cx = rng.randrange(P.Q_MOD)
+        if wire._sqrt_fq((cx ** 3 + 4) % P.Q_MOD) is None:
+            no_point = bytearray(cx.to_bytes(48, "big"))
+            no_point[0] |= 0x80
+    torsion = None
+    while torsion is None:
+        cx = rng.randrange(P.Q_MOD)
+        y = wire._sqrt_fq((cx ** 3 + 4) % P.Q_MOD)
+        if y is not None and not point_check("g1", np.concatenate([wire._fq_mont(cx), wire._fq_mont(y)])):
+            torsion = bytearray(cx.to_bytes(48, "big"))
+            torsion[0] |= 0x80 | (0x20 if y > (P.Q_MOD - y) % P.Q_MOD else 0)
+    q_enc = bytearray(P.Q_MOD.to_bytes(48, "big"))
+    q_enc[0] |= 0x80
+    hostile = [bytes([good[0] & 0x7F]) + good[1:],                       # compression bit cleared
+               bytes([0xC0]) + bytes(46) + b"\x01", bytes([0xE0]) + bytes(47),      # dirty infinity encodings
+               bytes(q_enc),                                             # x = q: not reduced
+               bytes(no_point), bytes(torsion)]
+    for i, h in enumerate(hostile):
+        with pytest.raises(ValueError):
+            wire.g1_decompress(h)
+        with pytest.raises(ValueError):
+            wire.g1_decompress_many(good + h, 2)
+    pts, _ = wire.g1_decompress_many(bytes(torsion), 1, validate=False)      # on the curve: only the subgroup test refuses it
+    assert np.array_equal(pts[0], wire.g1_decompress(bytes(torsion), validate=False)[0])
+    with pytest.raises(ValueError):
+        wire.g1_decompress_many(good, 2)                                 # length does not match the count
+
+
 def test_prepared_verifying_key_layout_round_trip_and_consistency():
     """encode_pvk (io.rs:62-68): VerifyingKey | Fq12 e(alpha, beta) | G2Prepared(-gamma) | G2Prepared(-delta).  Sizes follow
     ark's derive order; the Fq12 value is cross-checked against the independent pure-Python pairing (cube of the reduced pairing,

@@ -105,6 +105,32 @@ def g1_decompress(b, validate=True):
     return out, 0
 
 
+_G1_STATUS = {1: "not a compressed G1 point", 2: "non-canonical encoding of the point at infinity", 3: "x coordinate is not reduced",
+              4: "x not on curve", 5: "g1 point is not in the prime-order subgroup"}
+
+
+def g1_decompress_many(b, n, validate=True):
+    """n compressed G1 points back to back -> (n x 12 Montgomery limbs, n infinity flags), the rules of g1_decompress applied by the
+    library's host code (zkg16_g1_decompress): a verifying key with hundreds of gamma_abc_g1 points is decoded in a few ms instead
+    of ~0.2 ms of Python big-integer square root per point."""
+    import ctypes as C
+    from . import _lib
+    if len(b) != 48 * n:
+        raise ValueError("not %d compressed G1 points" % n)
+    raw = np.frombuffer(bytes(b), dtype=np.uint8)
+    out = np.zeros((n, 12), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    status = (C.c_int * max(n, 1))()
+    rc = _lib.load().zkg16_g1_decompress(raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p),
+                                        1 if validate else 0, status)
+    if rc:
+        for i in range(n):
+            if status[i]:
+                raise ValueError("G1 point %d: %s" % (i, _G1_STATUS.get(status[i], "invalid")))
+        raise ValueError("G1 decompression failed")
+    return out, inf
+
+
 def g2_decompress(b, validate=True):
     if len(b) != 96 or not b[0] & 0x80:
         raise ValueError("not a compressed G2 point")
@@ -195,7 +221,7 @@ def vk_deserialize_compressed(b):
     beta, _ = g2_decompress(b[48:144])
     gamma, _ = g2_decompress(b[144:240])
     delta, _ = g2_decompress(b[240:336])
-    gabc = np.array([g1_decompress(b[344 + 48 * i:392 + 48 * i])[0] for i in range(n)], dtype=np.uint64).reshape(n, 12)
+    gabc, ginf = g1_decompress_many(b[344:344 + 48 * n], n)          # (infinity decodes to zero limbs, as g1_decompress returns them)
     return dict(alpha_g1=a, beta_g2=beta, gamma_g2=gamma, delta_g2=delta, gamma_abc_g1=gabc)
 
 
