@@ -230,6 +230,8 @@ ZKG16_API int zkg16_prime_search(uint64_t x, uint64_t i_max, uint64_t *j_out, ui
 ZKG16_API int zkg16_prime_candidate(uint64_t x, uint64_t j, uint8_t digest_out[32], uint32_t *n_out, uint32_t bases_out[3],
                           uint8_t r_bytes_out[32], int *is_prime);
 ZKG16_API int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out);
+/* The PrimeCircuit's 257 public inputs (x, then the digest bits) without building the circuit: out = 257 x 4 limbs, Montgomery. */
+ZKG16_API int zkg16_prime_public_inputs(uint64_t x, uint64_t j, uint64_t *out);
 ZKG16_API void zkg16_circuit_free(zkg16_circuit *c);
 ZKG16_API int zkg16_circuit_dims(const zkg16_circuit *c, size_t *num_instance, size_t *num_witness, size_t *num_constraints, size_t nnz[3]);
 ZKG16_API int zkg16_circuit_is_satisfied(const zkg16_circuit *c);

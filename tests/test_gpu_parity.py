@@ -687,6 +687,33 @@ def test_setup_on_device_vs_oracle(dev, oracle, kind):
         f(hnd)
 
 
+def test_circuit_load_equals_export_then_load(dev):
+    """zkg16_circuit_load (a synthesized circuit straight to the device through the ctx's pinned staging block) leaves the same bytes
+    on the device as zkg16_circuit_export + zkg16_r1cs_load + zkg16_witness_load, and the same proof comes out; twice in a row with
+    different sizes (the staging block grows and is reused)."""
+    from zksnark_finalproject_amd.circuits import (fibonacci_circuit, fibonacci_circuit_handle, prime_circuit, prime_circuit_handle,
+                                                   prime_search)
+    from zksnark_finalproject_amd import handlers
+    j = prime_search(12345, 32)["j"]
+    cases = [(prime_circuit_handle(12345, j), prime_circuit(12345, j, search=False, check_satisfied=False)),
+             (fibonacci_circuit_handle(0, 1, 300), fibonacci_circuit(0, 1, 300)),
+             (prime_circuit_handle(99, prime_search(99, 32)["j"]), prime_circuit(99, 32, check_satisfied=False))]
+    for h, full in cases:
+        assert np.array_equal(h.public_inputs, full.public_inputs)
+        rh, wh = dev.circuit_load(h)
+        h.close()
+        got, nv = dev.r1cs_read(rh)
+        assert nv == full.num_vars and got["num_inputs"] == full.num_instance and got["num_constraints"] == full.num_constraints
+        for m in "abc":
+            assert all(np.array_equal(u, v) for u, v in zip(got[m], full.r1cs[m])), m
+        assert np.array_equal(dev.witness_read(wh, full.num_vars), full.z)
+        dev.r1cs_free(rh)
+        dev.witness_free(wh)
+    res = handlers.prove_prime(dev, 12345, 32)                # the handler's request path goes through zkg16_circuit_load
+    assert handlers.verify_prime(res["pvk"], 12345, res["j"], res["proof"])["valid"] is True
+    assert handlers.verify_prime(res["pvk"], 12346, res["j"], res["proof"])["valid"] is False
+
+
 def test_handler_mirrors_end_to_end(dev, oracle):
     """prove_matrix / prove_fibonacci (handlers.py: synthesize -> device setup -> device prove -> wire encoding): the proof
     the handler returns decodes to exactly the oracle's proof for the same key, r, s."""

@@ -64,6 +64,13 @@ def test_prime_circuit_shape_public_inputs_and_satisfaction(x):
     assert c2.num_constraints == c.num_constraints and np.array_equal(c2.z, c.z)
     for m in "abc":
         assert all(np.array_equal(u, v) for u, v in zip(c.r1cs[m], c2.r1cs[m]))
+    # the request path's forms of the same circuit: the handle that is never exported, and the public inputs without a circuit
+    from zksnark_finalproject_amd.circuits import prime_circuit_handle, prime_public_inputs
+    h = prime_circuit_handle(x, c.j)
+    assert (h.num_instance, h.num_witness, h.num_constraints, h.domain) == (c.num_instance, c.num_witness, c.num_constraints, c.domain)
+    assert np.array_equal(h.public_inputs, c.public_inputs)
+    h.close()
+    assert np.array_equal(prime_public_inputs(x, c.j), c.public_inputs)
 
 
 def test_perturbed_assignment_is_not_satisfied(oracle_free_eval=None):

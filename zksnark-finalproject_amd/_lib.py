@@ -66,6 +66,7 @@ SIGNATURES = {
     "zkg16_prime_search": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), u8p, C.POINTER(C.c_int)]),
     "zkg16_prime_candidate": (C.c_int, [C.c_uint64, C.c_uint64, u8p, C.POINTER(C.c_uint32), u32p, u8p, C.POINTER(C.c_int)]),
     "zkg16_circuit_prime": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "zkg16_prime_public_inputs": (C.c_int, [C.c_uint64, C.c_uint64, u64p]),
     "zkg16_circuit_free": (None, [vp]),
     "zkg16_circuit_dims": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz * 3)]),
     "zkg16_circuit_is_satisfied": (C.c_int, [vp]),

@@ -70,6 +70,15 @@ class CircuitHandle:
             pass
 
 
+def prime_public_inputs(x, j):
+    """The PrimeCircuit's public inputs for candidate j (x and the 256 digest bits), computed natively (zkg16_prime_public_inputs)."""
+    out = np.zeros((257, 4), dtype=np.uint64)
+    rc = _lib.load().zkg16_prime_public_inputs(x, j, out.reshape(-1))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_prime_public_inputs")
+    return out
+
+
 def prime_circuit_handle(x, j):
     """PrimeCircuit of candidate j as a CircuitHandle (nothing exported to Python)."""
     h = C.c_void_p()
@@ -148,6 +157,15 @@ def fibonacci_circuit(a, b, steps):
     if rc:
         raise Zkg16Error(rc, "zkg16_circuit_fibonacci")
     return SynthesizedCircuit(h)
+
+
+def fibonacci_circuit_handle(a, b, steps):
+    """FibonacciCircuit as a CircuitHandle (nothing exported to Python)."""
+    h = C.c_void_p()
+    rc = _lib.load().zkg16_circuit_fibonacci(a, b, steps, C.byref(h))
+    if rc:
+        raise Zkg16Error(rc, "zkg16_circuit_fibonacci")
+    return CircuitHandle(h)
 
 
 def prime_search(x, i_max):

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -839,6 +840,18 @@ int zkg16_prime_candidate(uint64_t x, uint64_t j, uint8_t digest_out[32], uint32
 }
 // PrimeCircuit::new(...) for the candidate at index j, as prove_prime builds it for the j it found and verify_prime
 // rebuilds it to recover the public inputs (prime_snark.rs:98-105, 170-193).  Instance: 1, x, the 256 digest bits.
+// The PrimeCircuit's public inputs for candidate j of x — x, then the 256 bits of SHA-256(x + j) (bit t of byte k at position
+// 8 k + t) — without building the circuit: what verify_prime (prime_snark.rs:165-206) re-synthesizes the whole circuit for.
+// out: 257 x 4 limbs, Montgomery.  (Checked against the instance of zkg16_circuit_prime in tests/test_prime_circuit.py.)
+int zkg16_prime_public_inputs(uint64_t x, uint64_t j, uint64_t *out) {
+    if (!out) return ZKG16_ERR_BAD_ARG;
+    const PrimeCandidate cand = prime_candidate(x, j);
+    Fr *o = reinterpret_cast<Fr *>(out);
+    o[0] = fr_from_u64(x);
+    for (int k = 0; k < 256; k++) o[1 + k] = ((cand.digest[k >> 3] >> (k & 7)) & 1) ? Fr::one() : Fr::zero();
+    return ZKG16_OK;
+}
+
 // The PrimeCircuit's storage (75 MB of rows and witness values, the same size for every request) kept between requests: fresh
 // vectors of that size come from mmap and every request paid ~18 k page faults — 20 to 45 ms on the GPU box's host, more than the
 // 14 ms the synthesis itself takes.  One set; a second concurrent build simply allocates.
@@ -882,7 +895,10 @@ int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
                 seg.witness.clear();
             }
         }
+        const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         build_prime_circuit(seg, x, j, cand);
+        if (trace) fprintf(stderr, "zkg16_circuit_prime: built in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         *out = c.release();
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;

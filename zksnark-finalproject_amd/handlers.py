@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import wire
-from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_circuit_handle, prime_search
+from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_circuit_handle, prime_public_inputs, prime_search
 from .workloads import R_MOD, g1_generator, g2_generator
 
 
@@ -181,12 +181,10 @@ def prove_prime(dev, x, i, seed=7, keep_key=False, check_satisfied=False):
 
 
 def verify_prime(vk, x, j, proof_b64):
-    """Mirror of verify_prime (prime_snark.rs:165-206): the verifier re-synthesizes PrimeCircuit for (x, j) to recover the
-    public inputs (x and the 256 digest bits), then checks the proof."""
-    circ = prime_circuit_handle(x, j)
-    pub = circ.public_inputs
-    circ.close()
-    return verify_proof(vk, pub, proof_b64)
+    """Mirror of verify_prime (prime_snark.rs:165-206): the reference re-synthesizes PrimeCircuit for (x, j) to recover the
+    public inputs (x and the 256 digest bits); here they are computed natively (the same values: test_prime_circuit.py), then
+    the proof is checked."""
+    return verify_proof(vk, prime_public_inputs(x, j), proof_b64)
 
 
 def verify_proof(vk, public_inputs_mont, proof_b64):
