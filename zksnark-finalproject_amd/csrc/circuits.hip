@@ -22,6 +22,7 @@
 #include <mutex>
 #include <new>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -494,6 +495,27 @@ static Lc poseidon_hash_chunked(std::vector<SpongeChunk> &ch, const std::vector<
     return res.back();
 }
 
+// helper threads of one build: joined on every exit path; a thread that cannot be started runs inline (never std::terminate)
+class ThreadGroupLocal {
+    std::vector<std::thread> th_;
+  public:
+    ThreadGroupLocal() = default;
+    ThreadGroupLocal(const ThreadGroupLocal &) = delete;
+    ThreadGroupLocal &operator=(const ThreadGroupLocal &) = delete;
+    template <class Fn>
+    void run(Fn fn) {
+        try {
+            th_.emplace_back(fn);
+        } catch (const std::system_error &) {
+            fn();
+        }
+    }
+    ~ThreadGroupLocal() {
+        for (auto &t : th_)
+            if (t.joinable()) t.join();
+    }
+};
+
 #include "prime_circuit.inc"
 
 }  // namespace
@@ -501,7 +523,7 @@ static Lc poseidon_hash_chunked(std::vector<SpongeChunk> &ch, const std::vector<
 struct zkg16_circuit {
     // segments in row order; segs[0] holds the instance variables.  Witness values: each segment's own, at its wit_base.
     std::vector<std::unique_ptr<Circuit>> segs;
-    bool pooled_storage = false;       // the PrimeCircuit's one segment: its vectors go back to prime_store() when it is freed
+    bool pooled_storage = false;       // the PrimeCircuit's per-part segments: their vectors go back to prime_store() when it is freed
     Circuit &head() { return *segs[0]; }
     const Circuit &head() const { return *segs[0]; }
     Circuit &add_segment(size_t wit_base) {
@@ -853,22 +875,56 @@ int zkg16_prime_public_inputs(uint64_t x, uint64_t j, uint64_t *out) {
 }
 
 // The PrimeCircuit's storage (75 MB of rows and witness values, the same size for every request) kept between requests: fresh
-// vectors of that size come from mmap and every request paid ~18 k page faults — 20 to 45 ms on the GPU box's host, more than the
-// 14 ms the synthesis itself takes.  One set; a second concurrent build simply allocates.
+// vectors of that size come from mmap and the first build of a process pays ~18 k page faults (90 ms on the GPU box's host against
+// the 18 ms of the synthesis itself).  One set of per-part vectors; a second concurrent build simply allocates.
 namespace {
 struct PrimeStore {
     std::mutex mu;
-    bool full = false;
-    std::vector<Fr> witness;
-    std::vector<Term> t[3];
-    std::vector<uint64_t> ptr[3];
+    struct Part {
+        bool full = false;
+        std::vector<Fr> witness;
+        std::vector<Term> t[3];
+        std::vector<uint64_t> ptr[3];
+    } part[PRIME_PARTS];
+    PrimeLayout layout;        // recorded by the first (sequential) build
 };
 PrimeStore &prime_store() {
     static PrimeStore s;
     return s;
 }
+void prime_store_take(Circuit &seg, int p) {
+    PrimeStore &st = prime_store();
+    std::lock_guard<std::mutex> lk(st.mu);
+    PrimeStore::Part &pt = st.part[p];
+    if (!pt.full) return;
+    pt.full = false;
+    seg.witness.swap(pt.witness);
+    seg.witness.clear();
+    for (int m = 0; m < 3; m++) {
+        seg.rows[m].t.swap(pt.t[m]);
+        seg.rows[m].ptr.swap(pt.ptr[m]);
+        seg.rows[m].t.clear();
+        seg.rows[m].ptr.assign(1, 0);
+    }
+}
+void prime_store_give(Circuit &seg, int p) {
+    PrimeStore &st = prime_store();
+    std::lock_guard<std::mutex> lk(st.mu);
+    PrimeStore::Part &pt = st.part[p];
+    if (pt.full) return;
+    pt.witness.swap(seg.witness);
+    for (int m = 0; m < 3; m++) {
+        pt.t[m].swap(seg.rows[m].t);
+        pt.ptr[m].swap(seg.rows[m].ptr);
+    }
+    pt.full = true;
+}
 }  // namespace
 
+// The first build of a process runs the seven parts of the circuit (prime_circuit.inc) one after another in a single segment and
+// records how many witnesses precede each part; every later build gives each part its own segment and thread.  The counts do not
+// depend on (x, j); should a part ever allocate a different number the build is repeated sequentially
+// (tests/test_prime_circuit.py compares both forms array by array).  ZKG16_SYNTH_THREADS=0: always sequential.
 int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
     if (!out) return ZKG16_ERR_BAD_ARG;
     *out = nullptr;
@@ -877,28 +933,63 @@ int zkg16_circuit_prime(uint64_t x, uint64_t j, zkg16_circuit **out) {
     for (int k = 0; k < PRIME_K; k++)
         if (cand.base[k] == 0) return ZKG16_ERR_UNSUPPORTED;  // base.inverse().unwrap() panics upstream
     try {
-        std::unique_ptr<zkg16_circuit> c(new zkg16_circuit());
-        Circuit &seg = c->add_segment(0);
-        c->pooled_storage = true;
+        const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const char *env = getenv("ZKG16_SYNTH_THREADS");
+        PrimeLayout lay;
         {
             PrimeStore &st = prime_store();
             std::lock_guard<std::mutex> lk(st.mu);
-            if (st.full) {
-                st.full = false;
-                seg.witness.swap(st.witness);
-                for (int m = 0; m < 3; m++) {
-                    seg.rows[m].t.swap(st.t[m]);
-                    seg.rows[m].ptr.swap(st.ptr[m]);
-                    seg.rows[m].t.clear();
-                    seg.rows[m].ptr.assign(1, 0);
+            lay = st.layout;
+        }
+        std::unique_ptr<zkg16_circuit> c;
+        bool parallel = lay.known && !(env && env[0] == '0') && std::thread::hardware_concurrency() > 1;
+        if (parallel) {
+            c.reset(new zkg16_circuit());
+            c->pooled_storage = true;
+            for (int p = 0; p < PRIME_PARTS; p++) {
+                Circuit &seg = c->add_segment(lay.wit_base[p]);
+                prime_store_take(seg, p);
+                seg.witness.reserve(lay.wit_base[p + 1] - lay.wit_base[p] + 16);
+                for (int m = 0; m < 3; m++) { seg.rows[m].t.reserve(lay.nnz_hint[p][m] + 64); seg.rows[m].ptr.reserve(lay.rows_hint[p] + 16); }
+            }
+            std::atomic<bool> failed{false};
+            {
+                ThreadGroupLocal tg;
+                for (int p = 1; p < PRIME_PARTS; p++)
+                    tg.run([&, p] {
+                        try {
+                            PrimeShared sh = lay.sh;
+                            prime_part(*c->segs[p], p, x, j, cand, sh);
+                        } catch (...) {
+                            failed = true;
+                        }
+                    });
+                try {
+                    PrimeShared sh = lay.sh;
+                    prime_part(*c->segs[0], 0, x, j, cand, sh);
+                } catch (...) {
+                    failed = true;
                 }
-                seg.witness.clear();
+            }
+            bool ok = !failed;
+            for (int p = 0; ok && p < PRIME_PARTS; p++) ok = c->segs[p]->witness.size() == lay.wit_base[p + 1] - lay.wit_base[p];
+            if (!ok) {
+                std::lock_guard<std::mutex> lk(prime_store().mu);
+                prime_store().layout.known = false;
+                parallel = false;
             }
         }
-        const bool trace = getenv("ZKG16_TRACE_HOST") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
-        build_prime_circuit(seg, x, j, cand);
-        if (trace) fprintf(stderr, "zkg16_circuit_prime: built in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (!parallel) {
+            c.reset(new zkg16_circuit());
+            Circuit &seg = c->add_segment(0);
+            PrimeLayout fresh;
+            build_prime_circuit(seg, x, j, cand, &fresh);
+            std::lock_guard<std::mutex> lk(prime_store().mu);
+            prime_store().layout = fresh;
+        }
+        if (trace) fprintf(stderr, "zkg16_circuit_prime: built in %.2f ms (%s)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                           parallel ? "seven threads" : "one thread");
         *out = c.release();
     } catch (const std::bad_alloc &) {
         return ZKG16_ERR_OOM;
@@ -1194,19 +1285,8 @@ int zkg16_circuit_matrix_witness(size_t n, const uint64_t *a, const uint64_t *b,
 
 void zkg16_circuit_free(zkg16_circuit *c) {
     if (!c) return;
-    if (c->pooled_storage && c->segs.size() == 1) {
-        PrimeStore &st = prime_store();
-        std::lock_guard<std::mutex> lk(st.mu);
-        if (!st.full) {
-            Circuit &seg = *c->segs[0];
-            st.witness.swap(seg.witness);
-            for (int m = 0; m < 3; m++) {
-                st.t[m].swap(seg.rows[m].t);
-                st.ptr[m].swap(seg.rows[m].ptr);
-            }
-            st.full = true;
-        }
-    }
+    if (c->pooled_storage && c->segs.size() == (size_t)PRIME_PARTS)
+        for (int p = 0; p < PRIME_PARTS; p++) prime_store_give(*c->segs[p], p);
     size_t terms = 0;
     for (const auto &sg : c->segs) terms += sg->rows[0].t.size() + sg->rows[1].t.size() + sg->rows[2].t.size();
     if (terms < (1u << 16)) {
