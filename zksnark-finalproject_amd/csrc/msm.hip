@@ -1082,7 +1082,9 @@ static void msm_enqueue_reduce(zkg16_ctx *ctx, MsmSlot &slot) {
     // (2 bits + 3) nwin sums: ~0.5 us per G1 and ~1.4 us per G2 operation, which smaller circuits cannot hide — 8x8: 4.4 -> 5.3 ms)
     slot.bit_sliced = 0;
     const bool pow2 = (plan.nb & (plan.nb - 1)) == 0;
-    const bool bs_auto = ctx->opt_reduce_mode == 3 && (plan.nwin == 1 ? plan.nb >= 256 && plan.nb <= ((size_t)1 << 19) : plan.nb >= 4096 && tb <= ((size_t)1 << 19));
+    // (the proof's LAST reduction is an exposed tail whatever its size: bit-sliced up to 2^22 buckets — 128x128's H, 2^21: 3.0 -> 1.6 ms)
+    const size_t one_set_max = slot.last_of_proof ? ((size_t)1 << 22) : ((size_t)1 << 19);
+    const bool bs_auto = ctx->opt_reduce_mode == 3 && (plan.nwin == 1 ? plan.nb >= 256 && plan.nb <= one_set_max : plan.nb >= 4096 && tb <= ((size_t)1 << 19));
     if (pow2 && plan.nb >= 8 && (ctx->opt_reduce_mode == 5 || bs_auto)) {
         auto log2z = [](size_t v) { int l = 0; while (((size_t)1 << l) < v) l++; return l; };
         // chunk size by depth in dependent additions: 2K - 1 in chunk_local, the first tree level in rounds of the resident lanes (a G2
