@@ -93,3 +93,27 @@ def test_perturbed_assignment_is_not_satisfied(oracle_free_eval=None):
     all_rows = range(c.num_constraints)
     hit = [i for i in all_rows if any(int(cc) == 2 for m in "abc" for cc in c.r1cs[m][1][int(c.r1cs[m][0][i]):int(c.r1cs[m][0][i + 1])])]
     assert hit and not all(row_val("a", i, bad) * row_val("b", i, bad) % R == row_val("c", i, bad) for i in hit)
+
+
+def test_threaded_build_equals_sequential_build(monkeypatch):
+    """zkg16_circuit_prime builds the circuit's seven parts on seven threads once a first (sequential) build has recorded how many
+    witnesses precede each part: the arrays and the assignment must be those of the sequential build, for several (x, j) incl. j = 0
+    (one non-zero fewer in C), and the pooled storage must not leak anything from one request into the next."""
+    from zksnark_finalproject_amd.circuits import prime_circuit, prime_search
+    cases = []
+    for x in (3, 5, 58405, (1 << 64) - 41):
+        f = prime_search(x, 32)
+        if f["found"]:
+            cases.append((x, f["j"]))
+    assert any(j == 0 for _, j in cases) and len(cases) >= 3
+    monkeypatch.setenv("ZKG16_SYNTH_THREADS", "0")
+    seq = [prime_circuit(x, j, search=False, check_satisfied=True) for x, j in cases]
+    monkeypatch.delenv("ZKG16_SYNTH_THREADS")
+    for rep in range(2):                                  # twice: the second round runs on the storage the first one gave back
+        for (x, j), ref in zip(cases, seq):
+            c = prime_circuit(x, j, search=False, check_satisfied=True)
+            assert c.satisfied is True and ref.satisfied is True
+            assert (c.num_instance, c.num_witness, c.num_constraints) == (ref.num_instance, ref.num_witness, ref.num_constraints)
+            assert np.array_equal(c.z, ref.z)
+            for m in "abc":
+                assert all(np.array_equal(u, v) for u, v in zip(c.r1cs[m], ref.r1cs[m])), (x, j, m)
