@@ -149,7 +149,7 @@ def profile_lookup(key):
     return None
 
 
-def cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs, headline_nc):
+def cpu_baseline(dev, args, gpu_proofs, key_inputs, rs, headline_nc):
     """Times the CPU oracle (a port of the arkworks algorithms; oracle/) directly: the 32x32 MatrixCircuit on all host threads
     (its proof is compared with the GPU's for the same key, r, s) and the 16x16 one on a single thread."""
     sys.path[:0] = [os.path.join(ROOT, "oracle")]
@@ -175,8 +175,8 @@ def cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs, headline_nc):
     out["cores"] = used
     out["measured"] = {"n": n, "constraints": circ.num_constraints, "seconds": dt, "proofs_per_sec": 1.0 / dt,
                        "constraints_per_sec": circ.num_constraints / dt, "cores": used}
-    if gpu_proof_n32 is not None and n == 32:
-        out["oracle_match"] = bool(np.array_equal(oproof, gpu_proof_n32[0]) and np.array_equal(oinf, gpu_proof_n32[1]))
+    if n in gpu_proofs:             # the GPU's proof of the same circuit under the same key, r, s
+        out["oracle_match"] = bool(np.array_equal(oproof, gpu_proofs[n][0]) and np.array_equal(oinf, gpu_proofs[n][1]))
     del pk
     n1 = args.cpu_1t_n
     circ1, pk1 = host_key(n1)
@@ -190,9 +190,11 @@ def cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs, headline_nc):
     # the metric's unit on the headline workload: scaled by constraint count from the all-threads measurement
     out["value"] = (circ.num_constraints / dt) / headline_nc
     out["sample"] = ("MEASURED: oracle prove of the %dx%d MatrixCircuit (%d constraints) in %.2f s on %d threads (OpenMP: one task per MSM "
-                     "window, as ark's `parallel` feature) and of the %dx%d one (%d constraints) in %.2f s on 1 thread; SCALED: `value` = the "
-                     "all-threads constraints/s divided by the headline circuit's %d constraints"
-                     % (n, n, circ.num_constraints, dt, used, n1, n1, circ1.num_constraints, dt1, headline_nc))
+                     "window, as ark's `parallel` feature) and of the %dx%d one (%d constraints) in %.2f s on 1 thread; %s"
+                     % (n, n, circ.num_constraints, dt, used, n1, n1, circ1.num_constraints, dt1,
+                        "`value` = that all-threads measurement: it IS the headline circuit (--cpu-sample-n = --matrix-n)" if circ.num_constraints == headline_nc else
+                        "SCALED: `value` = the all-threads constraints/s divided by the headline circuit's %d constraints (--cpu-sample-n %d measures "
+                        "the headline circuit itself: ~70 s)" % (headline_nc, args.matrix_n)))
     return out
 
 
@@ -516,12 +518,17 @@ def main():
 
     # ---- free the headline workload before the smaller legs
     headline_z = circ.z
+    headline_gpu_proof = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "matrix" and args.cpu_sample_n == args.matrix_n:
+        headline_gpu_proof = dev.prove_resident(ph, rh, wh, *rs[-1])      # what the CPU baseline's proof of the headline circuit must equal
     for f, h in ((dev.pk_free, ph), (dev.witness_free, wh), (dev.r1cs_free, rh)):
         f(h)
     del circ
 
     legs = []
-    gpu_proof_n32 = None
+    gpu_proofs = {}                 # matrix size -> the GPU's proof for (key_inputs, rs[-1]): what the CPU baseline's proof must equal
+    if headline_gpu_proof is not None:
+        gpu_proofs[args.matrix_n] = headline_gpu_proof
     if rank == 0 and world == 1 and args.workload == "matrix":
         for leg in [x.strip() for x in args.legs.split(",") if x.strip()]:
             try:
@@ -542,8 +549,8 @@ def main():
                 torch.cuda.synchronize()
                 d1 = (time.perf_counter() - t1) / k
                 pr, pi = dev.prove_resident(p_h, r_h, w_h, *rs[-1])
-                if wl == "matrix" and n == 32:
-                    gpu_proof_n32 = (pr, pi)
+                if wl == "matrix":
+                    gpu_proofs[n] = (pr, pi)
                 rec = {"workload": d_, "n": n if wl == "matrix" else leg, "ms_per_step": d1 * 1e3, "value": 1.0 / d1, "unit": "proofs/s", "steps": k,
                        "constraints_per_sec": c.num_constraints / d1, "proof_verified": bool(verify(v_k, c.public_inputs, pr, pi)),
                        "setup_resident_s": set_s, "host_synthesis_s": syn, "stage_ms_last_proof": dev.last_timings(),
@@ -680,7 +687,7 @@ def main():
             out["throughput_in_flight"] = in_flight
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(dev, args, gpu_proof_n32, key_inputs, rs[-1], shp["nc"])
+                out["cpu_baseline"] = cpu_baseline(dev, args, gpu_proofs, key_inputs, rs[-1], shp["nc"])
             except Exception as e:      # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
