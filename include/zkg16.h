@@ -200,6 +200,13 @@ ZKG16_API int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_ins
  * status (nullable, n ints): 0 ok, 1 not compressed, 2 non-canonical infinity, 3 x not reduced, 4 not on the curve, 5 not in the
  * subgroup; returns ZKG16_ERR_BAD_ARG if any point failed. */
 ZKG16_API int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status);
+/* The same for G2 (96 bytes = x.c1 || x.c0; out n x 24 limbs), the inverse for both groups (group 1 / 2; inf nullable), and the
+ * 48-byte little-endian canonical form of Fq values (the Fq12 and line coefficients of a prepared verifying key; from-bytes
+ * refuses values >= q). */
+ZKG16_API int zkg16_g2_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status);
+ZKG16_API int zkg16_points_compress(int group, const uint64_t *points, const uint8_t *inf, size_t n, uint8_t *out);
+ZKG16_API int zkg16_fq_to_le_bytes(const uint64_t *limbs, size_t n, uint8_t *out);
+ZKG16_API int zkg16_fq_from_le_bytes(const uint8_t *bytes, size_t n, uint64_t *out);
 ZKG16_API int zkg16_point_check(int group, const uint64_t *point, int *ok);
 
 /* prod_i e(P_i, Q_i) == 1 ?  Host-only (no ctx, no GPU).  g1: n x 12 limbs, g2: n x 24 limbs, flag bytes nullable.

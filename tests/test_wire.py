@@ -168,6 +168,71 @@ def test_native_g1_decompression_equals_python_rules():
         wire.g1_decompress_many(good, 2)                                 # length does not match the count
 
 
+def test_native_codecs_equal_python_rules():
+    """The library's host codecs (what keys and proofs are encoded and decoded with) against wire.py's pure-Python statement of the same
+    rules: G2 decompression (both signs, y.c1 = 0 ties, infinity, refusals), G1 / G2 compression, the 48-byte field encoding."""
+    import pytest
+    from zksnark_finalproject_amd import wire
+    rng = random.Random(99)
+    g2pts = [py_g2(P.g2_mul(rng.randrange(1, P.R_MOD)))[0] for _ in range(12)]
+    encs = [wire.g2_compress(p, 0) for p in g2pts] + [bytes([0xC0]) + bytes(95)]
+    got, ginf = wire.g2_decompress_many(b"".join(encs), len(encs))
+    for i, e in enumerate(encs):
+        want, winf = wire.g2_decompress(e)
+        assert winf == ginf[i] and np.array_equal(got[i], want), i
+    assert sum(1 for e in encs if e[0] & 0x20) not in (0, len(encs))
+    assert wire.points_compress("g2", np.stack(g2pts)) == b"".join(encs[:-1])
+    assert wire.points_compress("g2", np.zeros((1, 24), np.uint64), [1]) == encs[-1]
+    g1pts = [py_g1(P.g1_mul(rng.randrange(1, P.R_MOD)))[0] for _ in range(12)]
+    assert wire.points_compress("g1", np.stack(g1pts)) == b"".join(wire.g1_compress(p, 0) for p in g1pts)
+    assert wire.points_compress("g1", np.zeros((1, 12), np.uint64), [1]) == bytes([0xC0]) + bytes(47)
+    good = encs[0]
+    q_enc = bytearray(P.Q_MOD.to_bytes(48, "big") + bytes(48))
+    q_enc[0] |= 0x80
+    no_point = None
+    while no_point is None:
+        x0, x1 = rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD)
+        cand = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        cand[0] |= 0x80
+        try:
+            wire.g2_decompress(bytes(cand), validate=False)
+        except ValueError:
+            no_point = bytes(cand)
+    torsion = None
+    while torsion is None:
+        x0, x1 = rng.randrange(P.Q_MOD), rng.randrange(P.Q_MOD)
+        cand = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        cand[0] |= 0x80
+        try:
+            wire.g2_decompress(bytes(cand), validate=False)
+        except ValueError:
+            continue
+        try:
+            wire.g2_decompress(bytes(cand))
+        except ValueError:
+            torsion = bytes(cand)                                         # on the twist, outside the subgroup
+    hostile = [bytes([good[0] & 0x7F]) + good[1:], bytes([0xC0]) + bytes(94) + b"\x01", bytes([0xE0]) + bytes(95), bytes(q_enc),
+               good[:48] + P.Q_MOD.to_bytes(48, "big"),                  # x.c0 = q
+               no_point, torsion]
+    for h in hostile:
+        with pytest.raises(ValueError):
+            wire.g2_decompress(h)
+        with pytest.raises(ValueError):
+            wire.g2_decompress_many(good + h, 2)
+    pts, _ = wire.g2_decompress_many(torsion, 1, validate=False)
+    assert np.array_equal(pts[0], wire.g2_decompress(torsion, validate=False)[0])
+    # field encoding
+    vals = [0, 1, P.Q_MOD - 1, 2 ** 380] + [rng.randrange(P.Q_MOD) for _ in range(20)]
+    limbs = np.stack([wire._fq_mont(v) for v in vals])
+    raw = wire.fq_to_le_bytes(limbs)
+    assert raw == b"".join(v.to_bytes(48, "little") for v in vals)
+    assert np.array_equal(wire.fq_from_le_bytes(raw, len(vals)), limbs)
+    with pytest.raises(ValueError):
+        wire.fq_from_le_bytes(P.Q_MOD.to_bytes(48, "little"), 1)
+    with pytest.raises(ValueError):
+        wire.fq_from_le_bytes(raw[:-1], len(vals))
+
+
 def test_prepared_verifying_key_layout_round_trip_and_consistency():
     """encode_pvk (io.rs:62-68): VerifyingKey | Fq12 e(alpha, beta) | G2Prepared(-gamma) | G2Prepared(-delta).  Sizes follow
     ark's derive order; the Fq12 value is cross-checked against the independent pure-Python pairing (cube of the reduced pairing,

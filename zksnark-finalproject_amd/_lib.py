@@ -59,6 +59,10 @@ SIGNATURES = {
     "zkg16_verify_prepared": (C.c_int, [u64p, sz, vp, u64p, u64p, u64p, sz, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_point_check": (C.c_int, [C.c_int, u64p, C.POINTER(C.c_int)]),
     "zkg16_g1_decompress": (C.c_int, [vp, sz, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "zkg16_g2_decompress": (C.c_int, [vp, sz, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "zkg16_points_compress": (C.c_int, [C.c_int, vp, vp, sz, vp]),
+    "zkg16_fq_to_le_bytes": (C.c_int, [vp, sz, vp]),
+    "zkg16_fq_from_le_bytes": (C.c_int, [vp, sz, vp]),
     "zkg16_verify": (C.c_int, [u64p, u64p, u64p, u64p, u64p, sz, vp, u64p, u8p, C.POINTER(C.c_int)]),
     "zkg16_circuit_matrix": (C.c_int, [sz, u64p, u64p, C.POINTER(vp)]),
     "zkg16_circuit_matrix_witness": (C.c_int, [sz, u64p, u64p, u64p, sz]),

@@ -578,31 +578,100 @@ int zkg16_verify_prepared(const uint64_t *gamma_abc_g1, size_t num_instance, con
     return ZKG16_OK;
 }
 
-// n compressed G1 points (ark-serialize / zcash BLS12-381 encoding: 48 bytes, big-endian x, top bits = compressed, infinity, y is
-// the lexicographically larger root) -> affine Montgomery limbs, strict as `G1Affine::deserialize_compressed`.  status[i]: 0 ok,
-// 1 not a compressed encoding, 2 non-canonical infinity, 3 x not reduced, 4 x not on the curve, 5 not in the prime-order subgroup
-// (only with validate).  Returns ZKG16_OK when every point decoded.  (wire.py's pure-Python form of the same rules stays as the
-// reference the tests compare with; a verifying key with 258 points cost it 55 ms per request.)
-int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status) {
-    if ((!bytes || !out || !inf) && n) return ZKG16_ERR_BAD_ARG;
-    using zk::h64::Fq64;
-    namespace h = zk::h64;
-    // (q + 1) / 4 and q as 64-bit limbs
-    uint64_t q[6], e[6];
-    for (int i = 0; i < 6; i++) q[i] = Fq64::mod(i);
-    {
+// ---- the wire encodings of keys and proofs, natively (wire.py's pure-Python statement of the same rules is the reference the tests
+// compare these with; a prepared verifying key holds 816 Fq values, and a key of the prime handler 258 G1 points: 55 + 18 ms of
+// Python big-integer work per verify request, 2.5 ms of every prove request).
+namespace {
+using zk::h64::Fq64;
+namespace hq = zk::h64;
+struct FqConsts {
+    uint64_t q[6], e[6];       // q, (q + 1) / 4
+    Fq64 four;
+    FqConsts() {
+        for (int i = 0; i < 6; i++) q[i] = Fq64::mod(i);
         uint64_t carry = 1;
         for (int i = 0; i < 6; i++) { const uint64_t v = q[i] + carry; carry = v < carry ? 1 : 0; e[i] = v; }
         for (int i = 0; i < 6; i++) e[i] = (e[i] >> 2) | (i < 5 ? e[i + 1] << 62 : 0);
+        four = Fq64::zero();
+        four.l[0] = 4;
+        four = hq::to_mont(four);
     }
-    auto less = [](const uint64_t a[6], const uint64_t b[6]) {      // a < b
-        for (int i = 5; i >= 0; i--)
-            if (a[i] != b[i]) return a[i] < b[i];
+};
+const FqConsts &fq_consts() {
+    static const FqConsts c;
+    return c;
+}
+bool limbs_less(const uint64_t a[6], const uint64_t b[6]) {
+    for (int i = 5; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] < b[i];
+    return false;
+}
+// 48 big-endian bytes (the top three bits of byte 0 masked off when `flags`) -> canonical limbs; false if >= q
+bool fq_from_be(const uint8_t *b, bool flags, Fq64 &canon) {
+    for (int i = 0; i < 6; i++) {
+        uint64_t v = 0;
+        for (int t = 0; t < 8; t++) {
+            uint8_t byte = b[47 - (8 * i + t)];
+            if (flags && 8 * i + t == 47) byte &= 0x1F;
+            v |= (uint64_t)byte << (8 * t);
+        }
+        canon.l[i] = v;
+    }
+    return limbs_less(canon.l, fq_consts().q);
+}
+void fq_to_be(const Fq64 &mont, uint8_t *b) {
+    const Fq64 c = hq::from_mont(mont);
+    for (int i = 0; i < 6; i++)
+        for (int t = 0; t < 8; t++) b[47 - (8 * i + t)] = (uint8_t)(c.l[i] >> (8 * t));
+}
+// a^((q+1)/4) and whether it is a square root (q = 3 mod 4)
+bool fq_sqrt(const Fq64 &a, Fq64 &r) {
+    const FqConsts &k = fq_consts();
+    Fq64 y = Fq64::one();
+    bool started = false;
+    for (int i = 383; i >= 0; i--) {
+        if (started) y = hq::sqr(y);
+        if ((k.e[i / 64] >> (i % 64)) & 1) { y = started ? hq::mul(y, a) : a; started = true; }
+    }
+    r = y;
+    return hq::sqr(y) == a;
+}
+// y is the lexicographically larger of (y, -y): canonical y > q - y
+bool fq_is_largest(const Fq64 &y) {
+    const Fq64 yc = hq::from_mont(y), nyc = hq::from_mont(hq::neg(y));
+    return limbs_less(nyc.l, yc.l);
+}
+// square root in Fq[u] / (u^2 + 1), the complex method (wire.py _sqrt_fq2)
+bool fq2_sqrt(const Fq64 &a0, const Fq64 &a1, Fq64 &c0, Fq64 &c1) {
+    if (a1.is_zero()) {
+        Fq64 r;
+        if (fq_sqrt(a0, r)) { c0 = r; c1 = Fq64::zero(); return true; }
+        if (fq_sqrt(hq::neg(a0), r)) { c0 = Fq64::zero(); c1 = r; return true; }
         return false;
-    };
-    Fq64 four = Fq64::zero();
-    four.l[0] = 4;
-    four = h::to_mont(four);
+    }
+    Fq64 n;
+    if (!fq_sqrt(hq::add(hq::sqr(a0), hq::sqr(a1)), n)) return false;
+    Fq64 two = Fq64::zero();
+    two.l[0] = 2;
+    const Fq64 inv2 = hq::inv(hq::to_mont(two));
+    const Fq64 cand[2] = {hq::mul(hq::add(a0, n), inv2), hq::mul(hq::sub(a0, n), inv2)};
+    for (int t = 0; t < 2; t++) {
+        Fq64 r;
+        if (!fq_sqrt(cand[t], r) || r.is_zero()) continue;
+        const Fq64 i1 = hq::mul(a1, hq::inv(hq::dbl(r)));
+        if (hq::sub(hq::sqr(r), hq::sqr(i1)) == a0) { c0 = r; c1 = i1; return true; }
+    }
+    return false;
+}
+}  // namespace
+
+// n compressed G1 points (ark-serialize / zcash BLS12-381 encoding: 48 bytes, big-endian x, top bits = compressed, infinity, y is
+// the lexicographically larger root) -> affine Montgomery limbs, strict as `G1Affine::deserialize_compressed`.  status[i]: 0 ok,
+// 1 not a compressed encoding, 2 non-canonical infinity, 3 x not reduced, 4 x not on the curve, 5 not in the prime-order subgroup
+// (only with validate).  Returns ZKG16_OK when every point decoded.
+int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status) {
+    if ((!bytes || !out || !inf) && n) return ZKG16_ERR_BAD_ARG;
+    const FqConsts &kc = fq_consts();
     int bad = 0;
     for (size_t k = 0; k < n; k++) {
         const uint8_t *b = bytes + 48 * k;
@@ -617,30 +686,13 @@ int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *
             if (clean) inf[k] = 1; else st = 2;
         } else {
             Fq64 xc;
-            for (int i = 0; i < 6; i++) {
-                uint64_t v = 0;
-                for (int t = 0; t < 8; t++) {
-                    uint8_t byte = b[47 - (8 * i + t)];
-                    if (8 * i + t == 47) byte &= 0x1F;
-                    v |= (uint64_t)byte << (8 * t);
-                }
-                xc.l[i] = v;
-            }
-            if (!less(xc.l, q)) st = 3;
+            if (!fq_from_be(b, true, xc)) st = 3;
             else {
-                const Fq64 x = h::to_mont(xc);
-                const Fq64 rhs = h::add(h::mul(h::sqr(x), x), four);
-                Fq64 y = Fq64::one();
-                bool started = false;
-                for (int i = 383; i >= 0; i--) {
-                    if (started) y = h::sqr(y);
-                    if ((e[i / 64] >> (i % 64)) & 1) { y = started ? h::mul(y, rhs) : rhs; started = true; }
-                }
-                if (!(h::sqr(y) == rhs)) st = 4;
+                const Fq64 x = hq::to_mont(xc);
+                Fq64 y;
+                if (!fq_sqrt(hq::add(hq::mul(hq::sqr(x), x), kc.four), y)) st = 4;
                 else {
-                    const Fq64 yc = h::from_mont(y), nyc = h::from_mont(h::neg(y));
-                    const bool largest = less(nyc.l, yc.l);
-                    if (largest != ((b[0] & 0x20) != 0)) y = h::neg(y);
+                    if (fq_is_largest(y) != ((b[0] & 0x20) != 0)) y = hq::neg(y);
                     memcpy(o, x.l, 48);
                     memcpy(o + 6, y.l, 48);
                     if (validate && !g1_valid(load_pt<G1Affine>(o, 0))) st = 5;
@@ -651,6 +703,110 @@ int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *
         if (st) bad++;
     }
     return bad ? ZKG16_ERR_BAD_ARG : ZKG16_OK;
+}
+
+// the same for G2: 96 bytes = x.c1 || x.c0 big-endian, y compared as (c1, c0); out = n x 24 limbs (x.c0, x.c1, y.c0, y.c1)
+int zkg16_g2_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status) {
+    if ((!bytes || !out || !inf) && n) return ZKG16_ERR_BAD_ARG;
+    const FqConsts &kc = fq_consts();
+    int bad = 0;
+    for (size_t k = 0; k < n; k++) {
+        const uint8_t *b = bytes + 96 * k;
+        uint64_t *o = out + 24 * k;
+        int st = 0;
+        inf[k] = 0;
+        memset(o, 0, 24 * sizeof(uint64_t));
+        if (!(b[0] & 0x80)) st = 1;
+        else if (b[0] & 0x40) {
+            bool clean = b[0] == 0xC0;
+            for (int i = 1; i < 96; i++) clean = clean && b[i] == 0;
+            if (clean) inf[k] = 1; else st = 2;
+        } else {
+            Fq64 x1c, x0c;
+            if (!fq_from_be(b, true, x1c) || !fq_from_be(b + 48, false, x0c)) st = 3;
+            else {
+                const Fq64 x0 = hq::to_mont(x0c), x1 = hq::to_mont(x1c);
+                // x^3 + 4 (1 + u)
+                const Fq64 s0 = hq::sub(hq::sqr(x0), hq::sqr(x1)), s1 = hq::dbl(hq::mul(x0, x1));
+                const Fq64 c0 = hq::add(hq::sub(hq::mul(s0, x0), hq::mul(s1, x1)), kc.four);
+                const Fq64 c1 = hq::add(hq::add(hq::mul(s0, x1), hq::mul(s1, x0)), kc.four);
+                Fq64 y0, y1;
+                if (!fq2_sqrt(c0, c1, y0, y1)) st = 4;
+                else {
+                    // (y1, y0) > (-y1, -y0) lexicographically on canonical values
+                    const Fq64 ny0 = hq::neg(y0), ny1 = hq::neg(y1);
+                    const Fq64 y1c = hq::from_mont(y1), ny1c = hq::from_mont(ny1), y0c = hq::from_mont(y0), ny0c = hq::from_mont(ny0);
+                    bool largest;
+                    if (limbs_less(ny1c.l, y1c.l)) largest = true;
+                    else if (limbs_less(y1c.l, ny1c.l)) largest = false;
+                    else largest = limbs_less(ny0c.l, y0c.l);
+                    if (largest != ((b[0] & 0x20) != 0)) { y0 = ny0; y1 = ny1; }
+                    memcpy(o, x0.l, 48); memcpy(o + 6, x1.l, 48); memcpy(o + 12, y0.l, 48); memcpy(o + 18, y1.l, 48);
+                    if (validate && !g2_valid(load_pt<G2Affine>(o, 0))) st = 5;
+                }
+            }
+        }
+        if (status) status[k] = st;
+        if (st) bad++;
+    }
+    return bad ? ZKG16_ERR_BAD_ARG : ZKG16_OK;
+}
+
+// n affine points (Montgomery limbs; inf[i] != 0 = the point at infinity) -> compressed bytes (48 / 96 per point)
+int zkg16_points_compress(int group, const uint64_t *points, const uint8_t *inf, size_t n, uint8_t *out) {
+    if ((group != 1 && group != 2) || ((!points || !out) && n)) return ZKG16_ERR_BAD_ARG;
+    const size_t w = group == 1 ? 12 : 24, nb = group == 1 ? 48 : 96;
+    for (size_t k = 0; k < n; k++) {
+        uint8_t *b = out + nb * k;
+        if (inf && inf[k]) {
+            memset(b, 0, nb);
+            b[0] = 0xC0;
+            continue;
+        }
+        const uint64_t *p = points + w * k;
+        if (group == 1) {
+            Fq64 x, y;
+            memcpy(x.l, p, 48); memcpy(y.l, p + 6, 48);
+            fq_to_be(x, b);
+            b[0] |= 0x80 | (fq_is_largest(y) ? 0x20 : 0);
+        } else {
+            Fq64 x0, x1, y0, y1;
+            memcpy(x0.l, p, 48); memcpy(x1.l, p + 6, 48); memcpy(y0.l, p + 12, 48); memcpy(y1.l, p + 18, 48);
+            fq_to_be(x1, b);
+            fq_to_be(x0, b + 48);
+            const Fq64 y1c = hq::from_mont(y1), ny1c = hq::from_mont(hq::neg(y1));
+            bool largest;
+            if (limbs_less(ny1c.l, y1c.l)) largest = true;
+            else if (limbs_less(y1c.l, ny1c.l)) largest = false;
+            else largest = fq_is_largest(y0);
+            b[0] |= 0x80 | (largest ? 0x20 : 0);
+        }
+    }
+    return ZKG16_OK;
+}
+
+// n Fq values, Montgomery limbs <-> 48 little-endian canonical bytes each (ark's field serialization: the Fq12 and the line
+// coefficients of a prepared verifying key); from-bytes refuses values >= q (status ZKG16_ERR_BAD_ARG)
+int zkg16_fq_to_le_bytes(const uint64_t *limbs, size_t n, uint8_t *out) {
+    if ((!limbs || !out) && n) return ZKG16_ERR_BAD_ARG;
+    for (size_t k = 0; k < n; k++) {
+        Fq64 v;
+        memcpy(v.l, limbs + 6 * k, 48);
+        const Fq64 c = hq::from_mont(v);
+        memcpy(out + 48 * k, c.l, 48);          // little-endian host: canonical limbs are the bytes
+    }
+    return ZKG16_OK;
+}
+int zkg16_fq_from_le_bytes(const uint8_t *bytes, size_t n, uint64_t *out) {
+    if ((!bytes || !out) && n) return ZKG16_ERR_BAD_ARG;
+    for (size_t k = 0; k < n; k++) {
+        Fq64 c;
+        memcpy(c.l, bytes + 48 * k, 48);
+        if (!limbs_less(c.l, fq_consts().q)) return ZKG16_ERR_BAD_ARG;
+        const Fq64 m = hq::to_mont(c);
+        memcpy(out + 6 * k, m.l, 48);
+    }
+    return ZKG16_OK;
 }
 
 // curve + prime-order-subgroup membership of one affine point (group: 1 = G1, 2 = G2); *ok = 1 iff both hold

@@ -113,22 +113,72 @@ def g1_decompress_many(b, n, validate=True):
     """n compressed G1 points back to back -> (n x 12 Montgomery limbs, n infinity flags), the rules of g1_decompress applied by the
     library's host code (zkg16_g1_decompress): a verifying key with hundreds of gamma_abc_g1 points is decoded in a few ms instead
     of ~0.2 ms of Python big-integer square root per point."""
+    return _decompress_many("g1", b, n, validate)
+
+
+def _decompress_many(group, b, n, validate=True):
     import ctypes as C
     from . import _lib
-    if len(b) != 48 * n:
-        raise ValueError("not %d compressed G1 points" % n)
+    size, width = (48, 12) if group == "g1" else (96, 24)
+    if len(b) != size * n:
+        raise ValueError("not %d compressed %s points" % (n, group.upper()))
     raw = np.frombuffer(bytes(b), dtype=np.uint8)
-    out = np.zeros((n, 12), dtype=np.uint64)
+    out = np.zeros((n, width), dtype=np.uint64)
     inf = np.zeros(n, dtype=np.uint8)
     status = (C.c_int * max(n, 1))()
-    rc = _lib.load().zkg16_g1_decompress(raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p),
-                                        1 if validate else 0, status)
+    fn = _lib.load().zkg16_g1_decompress if group == "g1" else _lib.load().zkg16_g2_decompress
+    rc = fn(raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p), 1 if validate else 0, status)
     if rc:
         for i in range(n):
             if status[i]:
-                raise ValueError("G1 point %d: %s" % (i, _G1_STATUS.get(status[i], "invalid")))
-        raise ValueError("G1 decompression failed")
+                raise ValueError("%s point %d: %s" % (group.upper(), i, _G1_STATUS.get(status[i], "invalid").replace("G1", group.upper()).replace("g1", group)))
+        raise ValueError("%s decompression failed" % group.upper())
     return out, inf
+
+
+def g2_decompress_many(b, n, validate=True):
+    """n compressed G2 points back to back -> (n x 24 limbs, infinity flags) by the library's host code (zkg16_g2_decompress)."""
+    return _decompress_many("g2", b, n, validate)
+
+
+def points_compress(group, points, inf=None):
+    """(n x 12 | n x 24 Montgomery limbs, optional infinity flags) -> the compressed bytes back to back (zkg16_points_compress)."""
+    import ctypes as C
+    from . import _lib
+    width, size = (12, 48) if group == "g1" else (24, 96)
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, width)
+    n = pts.shape[0]
+    flags = np.zeros(n, dtype=np.uint8) if inf is None else np.ascontiguousarray(inf, dtype=np.uint8).reshape(n)
+    out = np.zeros(size * n, dtype=np.uint8)
+    rc = _lib.load().zkg16_points_compress(1 if group == "g1" else 2, pts.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), n,
+                                          out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError("point compression failed")
+    return out.tobytes()
+
+
+def fq_to_le_bytes(limbs):
+    """n x 6 Montgomery limbs -> 48 n bytes, little-endian canonical (zkg16_fq_to_le_bytes)."""
+    import ctypes as C
+    from . import _lib
+    v = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 6)
+    out = np.zeros(48 * v.shape[0], dtype=np.uint8)
+    if _lib.load().zkg16_fq_to_le_bytes(v.ctypes.data_as(C.c_void_p), v.shape[0], out.ctypes.data_as(C.c_void_p)):
+        raise ValueError("field serialization failed")
+    return out.tobytes()
+
+
+def fq_from_le_bytes(b, n):
+    """48 n little-endian canonical bytes -> n x 6 Montgomery limbs; refuses a value >= q (zkg16_fq_from_le_bytes)."""
+    import ctypes as C
+    from . import _lib
+    if len(b) != 48 * n:
+        raise ValueError("not %d field elements" % n)
+    raw = np.frombuffer(bytes(b), dtype=np.uint8)
+    out = np.zeros((n, 6), dtype=np.uint64)
+    if _lib.load().zkg16_fq_from_le_bytes(raw.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)):
+        raise ValueError("field element is not reduced")
+    return out
 
 
 def g2_decompress(b, validate=True):
@@ -162,16 +212,15 @@ def g2_decompress(b, validate=True):
 def proof_serialize_compressed(proof48, inf3):
     """(A | B | C affine Montgomery limbs, infinity flags) -> 192 bytes (io.rs:45-51 before base64)."""
     p = np.asarray(proof48, dtype=np.uint64)
-    return g1_compress(p[:12], inf3[0]) + g2_compress(p[12:36], inf3[1]) + g1_compress(p[36:], inf3[2])
+    return (points_compress("g1", p[:12], [inf3[0]]) + points_compress("g2", p[12:36], [inf3[1]]) + points_compress("g1", p[36:], [inf3[2]]))
 
 
 def proof_deserialize_compressed(b):
     if len(b) != 192:
         raise ValueError("a compressed proof is 192 bytes")
-    a, ia = g1_decompress(b[:48])
-    bb, ib = g2_decompress(b[48:144])
-    c, ic = g1_decompress(b[144:])
-    return np.concatenate([a, bb, c]), np.array([ia, ib, ic], dtype=np.uint8)
+    ac, iac = g1_decompress_many(bytes(b[:48]) + bytes(b[144:]), 2)
+    bb, ib = g2_decompress_many(b[48:144], 1)
+    return np.concatenate([ac[0], bb[0], ac[1]]), np.array([iac[0], ib[0], iac[1]], dtype=np.uint8)
 
 
 def encode_proof(proof48, inf3):
@@ -199,11 +248,8 @@ def vk_serialize_compressed(vk):
     len(gamma_abc_g1) as u64 LE | gamma_abc_g1 (48 each)   (ark-groth16 data_structures.rs field order; Vec = u64 length
     prefix).  The reference ships the *prepared* key: pvk_serialize_compressed below."""
     gabc = np.asarray(vk["gamma_abc_g1"], dtype=np.uint64).reshape(-1, 12)
-    out = g1_compress(vk["alpha_g1"], 0) + g2_compress(vk["beta_g2"], 0) + g2_compress(vk["gamma_g2"], 0) + g2_compress(vk["delta_g2"], 0)
-    out += len(gabc).to_bytes(8, "little")
-    for p in gabc:
-        out += g1_compress(p, 0)
-    return out
+    g2s = np.stack([np.asarray(vk[k], dtype=np.uint64).reshape(24) for k in ("beta_g2", "gamma_g2", "delta_g2")])
+    return (points_compress("g1", vk["alpha_g1"]) + points_compress("g2", g2s) + len(gabc).to_bytes(8, "little") + points_compress("g1", gabc))
 
 
 # Untrusted bytes: every length prefix is checked against the bytes that are actually there BEFORE anything is allocated
@@ -217,12 +263,9 @@ def vk_deserialize_compressed(b):
     n = int.from_bytes(b[336:344], "little")
     if n < 1 or n > _MAX_INSTANCE or len(b) != 344 + 48 * n:
         raise ValueError("verifying key length does not match its gamma_abc_g1 count")
-    a, _ = g1_decompress(b[:48])
-    beta, _ = g2_decompress(b[48:144])
-    gamma, _ = g2_decompress(b[144:240])
-    delta, _ = g2_decompress(b[240:336])
-    gabc, ginf = g1_decompress_many(b[344:344 + 48 * n], n)          # (infinity decodes to zero limbs, as g1_decompress returns them)
-    return dict(alpha_g1=a, beta_g2=beta, gamma_g2=gamma, delta_g2=delta, gamma_abc_g1=gabc)
+    g1s, _ = g1_decompress_many(bytes(b[:48]) + bytes(b[344:344 + 48 * n]), n + 1)          # (infinity decodes to zero limbs)
+    g2s, _ = g2_decompress_many(b[48:336], 3)
+    return dict(alpha_g1=g1s[0], beta_g2=g2s[0], gamma_g2=g2s[1], delta_g2=g2s[2], gamma_abc_g1=g1s[1:])
 
 
 def encode_vk(vk):
@@ -252,17 +295,13 @@ def _fq_from_le(b):
 
 def _prepared_bytes(coeffs):
     c = np.asarray(coeffs, dtype=np.uint64).reshape(-1, 36)
-    out = len(c).to_bytes(8, "little")
-    for row in c:
-        out += b"".join(_fq_le(row[6 * k:6 * k + 6]) for k in range(6))
-    return out + b"\x00"                     # infinity = false
+    return len(c).to_bytes(8, "little") + fq_to_le_bytes(c.reshape(-1, 6)) + b"\x00"                     # infinity = false
 
 
 def pvk_serialize_compressed(pvk):
     """pvk: device.pvk_prepare(vk) -> bytes."""
     ab = np.asarray(pvk["alpha_beta"], dtype=np.uint64)
-    return (vk_serialize_compressed(pvk) + b"".join(_fq_le(ab[6 * k:6 * k + 6]) for k in range(12)) +
-            _prepared_bytes(pvk["gamma_neg_pc"]) + _prepared_bytes(pvk["delta_neg_pc"]))
+    return (vk_serialize_compressed(pvk) + fq_to_le_bytes(ab.reshape(12, 6)) + _prepared_bytes(pvk["gamma_neg_pc"]) + _prepared_bytes(pvk["delta_neg_pc"]))
 
 
 PVK_COEFFS = 68          # line-coefficient triples of a BLS12-381 G2Prepared (63 doublings + 5 additions of |z|)
@@ -278,17 +317,15 @@ def pvk_deserialize_compressed(b):
     if len(b) != off + 576 + 2 * (8 + 288 * PVK_COEFFS + 1):
         raise ValueError("prepared verifying key length does not match its counts")
     pvk = vk_deserialize_compressed(b[:off])
-    pvk["alpha_beta"] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(12)])
+    pvk["alpha_beta"] = fq_from_le_bytes(b[off:off + 576], 12).reshape(72)
     off += 576
     for name in ("gamma_neg_pc", "delta_neg_pc"):
         m = int.from_bytes(b[off:off + 8], "little")
         off += 8
         if m != PVK_COEFFS or off + 288 * m + 1 > len(b):
             raise ValueError("G2Prepared coefficient count is not %d" % PVK_COEFFS)
-        rows = np.zeros((m, 36), dtype=np.uint64)
-        for i in range(m):
-            rows[i] = np.concatenate([_fq_from_le(b[off + 48 * k:off + 48 * k + 48]) for k in range(6)])
-            off += 288
+        rows = fq_from_le_bytes(b[off:off + 288 * m], 6 * m).reshape(m, 36)
+        off += 288 * m
         if b[off] not in (0, 1) or (b[off] == 1) != (m == 0):
             raise ValueError("inconsistent G2Prepared infinity flag")
         off += 1
