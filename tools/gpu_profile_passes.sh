@@ -1,3 +1,4 @@
+# rocprofv3 passes of the 128x128 prove loop: kernel stats, SQ counters (two passes), FETCH_SIZE, WRITE_SIZE (each PMC pass on its own)
 set -x
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
