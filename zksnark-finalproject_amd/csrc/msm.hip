@@ -637,7 +637,8 @@ fixed_base_kernel(const Affine<FU> *table, const uint32_t *scalars, size_t n, XY
         const uint32_t d = (uint32_t)(two >> (bit & 31)) & (uint32_t)per;
         if (d) {
             const Affine<FU> p = ldv(table + (size_t)w * (size_t)per + (d - 1));
-            xyzz_madd(acc, p, false);
+            if constexpr (FieldTraits<FU>::g2) xyzz_madd_lazy(acc, p, false);      // one reduction per Fq2 component (one wave per block: ffu.cuh)
+            else xyzz_madd(acc, p, false);
         }
     }
     stv(out + i, acc);
