@@ -25,9 +25,11 @@ print(desc + ("  [window tables per shard]" if tables else ""), flush=True)
 single = None
 if 1 not in Gs:
     Gs = [1] + Gs
+ks = [int(x) for a in sys.argv[4:] if a.startswith("k=") for x in a[2:].split(",")]      # k=4,5: also time these witness-map rank counts (cost-based z cuts)
 for G in Gs:
-    for force in ([0] if G == 1 else [0, G]):
-        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, force, None if force else costs, window_tables=tables)
+    for force in ([0] if G == 1 else [0, G] + [-kk for kk in ks if kk < G]):
+        by_cost = force <= 0
+        plan, k = shard_plan(G, c.num_vars, c.domain - 1, 0.0, abs(force), costs if by_cost else None, window_tables=tables)
         worst = 0.0
         per_rank = []
         seen = {}
@@ -51,4 +53,4 @@ for G in Gs:
         if G == 1:
             single = worst
         print("n=%d G=%d witness-map ranks k=%d%s: per-rank ms %s -> slowest %.2f ms, speed-up %.2fx" %
-              (n, G, k, " (forced: equal split)" if force else " (cost model)", [round(x, 2) for x in per_rank], worst, single / worst), flush=True)
+              (n, G, k, " (forced: equal split)" if force > 0 else " (forced k, cost-based z cuts)" if force < 0 else " (cost model)", [round(x, 2) for x in per_rank], worst, single / worst), flush=True)

@@ -1161,7 +1161,7 @@ int zkg16_shard_plan_tables(int n_ranks, size_t m_total, size_t n_h, double b_de
     // 23.8 ms (the witness map) + 1.2 ms + 46.0 ms x its fraction of h_query (41.2 ms with tables).  In additions at 6.2 G/s:
     // z side 1.33x (1.19x) its additions, h side 1.13x (1.015x), witness map 8.8 per domain element.
     constexpr double KAPPA = 2.8, OMEGA = 8.8;
-    const double Z_OVERHEAD = window_tables ? 1.19 : 1.33, H_OVERHEAD = window_tables ? 1.015 : 1.13;
+    const double Z_OVERHEAD = window_tables ? 1.19 : 1.33, H_OVERHEAD = window_tables ? 0.965 : 1.13;
     const int G = n_ranks;
     const double Wz = 254 / default_window_bits(m_total + 3) + 1, Wh = n_h ? 254 / default_window_bits(n_h) + 1 : 0;
     // z-side work: uniform model, or the caller's per-index costs (in G1 mixed additions: entries of the scalar times the
@@ -1176,9 +1176,12 @@ int zkg16_shard_plan_tables(int n_ranks, size_t m_total, size_t n_h, double b_de
     Z *= Z_OVERHEAD;
     const double H = H_OVERHEAD * (double)n_h * Wh, WM = n_h ? OMEGA * (double)(n_h + 1) : 0.0;
     // fixed cost of taking part at all (latency chains that do not shrink with the share: the scatter passes and the four / one
-    // bucket reductions): ~3.5 ms for the z side, ~1.15 ms for the h side, in additions at 6.2 G/s.  With them a rank whose time
+    // bucket reductions): ~1.9 ms for the z side, ~0.5 ms for the h side, in additions at 6.2 G/s.  With them a rank whose time
     // is used up by the witness map and its h share takes no z work at all, and small circuits use fewer witness-map ranks.
-    constexpr double F_Z = 21.7e6, F_H = 7.0e6;
+    // (round 3, profiles/shard_calibration_r3.txt: with the bit-sliced reductions a z-only shard takes 1.9 ms + 96.8 ms x its fraction,
+    // an h-only one 24.26 ms (the witness map + 0.46 ms) + 39.1 ms x its fraction: round 2's 3.5 / 1.15 ms became 1.9 / 0.46, and the
+    // h-side factor with tables 0.965 — with 1.5 ms / 1.015 the model preferred five witness-map ranks of eight, measured 36.0 against 34.5 ms)
+    constexpr double F_Z = 11.8e6, F_H = 2.9e6;
     // time of the plan with k witness-map ranks: smallest T with  sum_i max(0, T - busy_i - F_Z) >= Z,  busy_i = WM + F_H + H/k (i < k)
     auto busy_of = [&](int k, int i) { return i < k ? WM + (n_h ? F_H : 0.0) + H / k : 0.0; };
     auto T_of = [&](int k) {
