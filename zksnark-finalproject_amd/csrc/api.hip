@@ -909,9 +909,9 @@ int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
         ctx->opt_wm_concurrent = (int)value;
         return ZKG16_OK;
     }
-    if (!strcmp(name, "ntt_radix")) {          // 2 (default; also 0): one butterfly stage per LDS trip; 4: two (radix 4)
-        if (value != 0 && value != 2 && value != 4) return ZKG16_ERR_BAD_ARG;
-        ctx->opt_ntt_radix = value == 4 ? 4 : 2;
+    if (!strcmp(name, "ntt_radix")) {          // 1 (default; also 0): the last seven stages by lane exchanges, the others one per LDS trip; 2: every stage through the LDS; 4: two per trip (radix 4)
+        if (value != 0 && value != 1 && value != 2 && value != 4) return ZKG16_ERR_BAD_ARG;
+        ctx->opt_ntt_radix = value == 4 ? 4 : value == 2 ? 2 : 1;
         return ZKG16_OK;
     }
     if (!strcmp(name, "ntt_xcd")) {            // 1 (default): XCD-aware tile order in the NTT passes; 2 = off (0 restores the default)

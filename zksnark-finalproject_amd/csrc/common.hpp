@@ -276,7 +276,7 @@ struct zkg16_ctx {
     int opt_window_bits_h = 0;                        // the H MSM's own plan (it is the last one: its reduction is not hidden)
     int opt_reduce_chunk = 0;
     int opt_wm_concurrent = -1;
-    int opt_ntt_radix = 2;                            // butterfly stages per trip through the LDS: 2 = one (default), 4 = two (radix 4: measured slower at 2^24, equal below)
+    int opt_ntt_radix = 1;                            // 1 (default): the last seven butterfly stages by lane exchanges (ds_bpermute / DPP), 2: every stage through the LDS, 4: two stages per LDS trip
     int opt_ntt_xcd = 1;                              // NTT tiles in XCD-aware order (ntt.hip: xcd_tile)
     int opt_acc_debug = 0;                            // timing probes (wrong results): see AccArgs::debug
     int opt_sort_mode = 0;                            // 0: hand-written bucket scatter (bucket_sort.hip), 1: rocPRIM radix sort

@@ -257,11 +257,113 @@ __device__ __forceinline__ void bfly_u(FrU &x, FrU &y, const FrU &tw) {
 // i + h, i + 3h/2 of a stage pair in registers, so the tile is read and written log_m / 2 times and the barriers halve; the
 // multiplications are the same four per group.  Measured: equal to one stage per trip up to 2^22, SLOWER at 2^24 (3.44 vs
 // 3.07 ms per transform: the kernel is multiplier-bound, and the four live elements cost registers), so it is not the default.
-template <int TL, bool GTW, bool R4>
+// MODE 2 (option "ntt_radix" = 1): the last (up to) seven stages without the LDS — a thread keeps its pair in registers and, between
+// two stages, swaps ONE element with the lane that holds the partner of the next stage (lane ^ 2^(s-1): ds_bpermute moves
+// registers between lanes of a wave, no LDS memory, no barrier); the stages above stay as they are.  
+// the value of lane ^ MASK: DPP quad permutes for 1 and 2 (a VALU move), ds_swizzle for 4 / 8 / 16 (no address register),
+// ds_bpermute for 32
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    else if constexpr (MASK == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    else if constexpr (MASK == 4 || MASK == 8 || MASK == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (MASK << 10) | 0x1F);
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)v);
+#else
+    (void)lane;
+    return v;
+#endif
+}
+template <int MASK>
+__device__ __forceinline__ FrU lane_xchg_u(const FrU &v, int lane) {
+    FrU r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = lane_xor_u32<MASK>(v.l[k], lane);
+    return r;
+}
+// one in-register stage ST of the chain below: the butterfly, then (ST > 0) the exchange that forms the pairs of stage ST - 1
+template <int TL, bool GTW, int ST>
+__device__ __forceinline__ void chain_stage_u(FrU &x, FrU &y, int &ex, int lane, const uint32_t *s_tw, int tw_stride, int log_m, const NttPassArgs &a) {
+    if constexpr (ST > 0) {
+        const int j = ex & ((1 << ST) - 1);
+        FrU tw;
+        if constexpr (GTW) {           // the 64 twiddles the chain can ask for (w_M^(j' 2^(log_m - 7))) were staged in LDS: [9][64]
+            const int jj = j << (6 - ST);
+#pragma unroll
+            for (int k = 0; k < 9; k++) tw.l[k] = s_tw[k * 64 + jj];
+        } else {
+            tw = tw_u<TL, GTW>(s_tw, tw_stride, j << (log_m - 1 - ST), log_m, a);
+        }
+        bfly_u<false>(x, y, tw);
+        // next stage pairs elements that differ in bit ST - 1: the lane with that bit clear keeps x and takes the partner's x as
+        // its y; the lane with it set keeps y and takes the partner's y as its x
+        const bool hi = (lane >> (ST - 1)) & 1;
+        FrU send;
+#pragma unroll
+        for (int k = 0; k < 9; k++) send.l[k] = hi ? x.l[k] : y.l[k];
+        const FrU recv = lane_xchg_u<(1 << (ST - 1))>(send, lane);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (hi) x.l[k] = recv.l[k]; else y.l[k] = recv.l[k];
+        }
+        if (hi) ex += 1 << (ST - 1);
+    } else {
+        bfly_u<true>(x, y, x);
+    }
+}
+
+template <int TL, bool GTW, int R4>
 __device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride, const NttPassArgs &a) {
     constexpr int TILE = 1 << TL;
     const int tid = threadIdx.x;
     int s = log_m - 1;
+    if (R4 == 2) {
+        if (log_m < 1) return;                                   // a one-point sub-transform: nothing to do
+        const int s_first = log_m - 1 < 6 ? log_m - 1 : 6;      // stages s_first .. 0 in registers
+        if (GTW && tid < 64) {          // (log_m >= 11 on this path) the chain's twiddles, read once per block instead of once per butterfly
+            uint32_t *tws = const_cast<uint32_t *>(s_tw);
+            const unsigned nmask = (1u << a.log_n) - 1u;
+            unsigned idx = ((unsigned)tid << (log_m - 7)) << (a.log_n - log_m);
+            if (a.inverse) idx = ((1u << a.log_n) - idx) & nmask;
+            const uint32_t *t = a.wu + (size_t)idx * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) tws[k * 64 + tid] = t[k];
+        }
+        for (; s > s_first; s--) {                               // the stages above: through the LDS, as MODE 0
+            const int h = 1 << s;
+            for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
+                const int c = u >> (log_m - 1);
+                const int v = u & ((1 << (log_m - 1)) - 1);
+                const int j = v & (h - 1);
+                const int blk = v >> s;
+                const int i0 = (c << log_m) + (blk << (s + 1)) + j;
+                FrU x = lds_ld_u(s_data, TILE, i0), y = lds_ld_u(s_data, TILE, i0 + h);
+                bfly_u<false>(x, y, tw_u<TL, GTW>(s_tw, tw_stride, j << (log_m - 1 - s), log_m, a));
+                lds_st_u(s_data, TILE, i0, x);
+                lds_st_u(s_data, TILE, i0 + h, y);
+            }
+            __syncthreads();
+        }
+        const int lane = tid & 63;
+        for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
+            const int c = u >> (log_m - 1);
+            const int v = u & ((1 << (log_m - 1)) - 1);
+            // the pair of stage s_first: bit s_first of the element index clear / set, the other bits from v
+            int ex = (c << log_m) + ((v >> s_first) << (s_first + 1)) + (v & ((1 << s_first) - 1));
+            FrU x = lds_ld_u(s_data, TILE, ex), y = lds_ld_u(s_data, TILE, ex + (1 << s_first));
+            if (s_first >= 6) chain_stage_u<TL, GTW, 6>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            if (s_first >= 5) chain_stage_u<TL, GTW, 5>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            if (s_first >= 4) chain_stage_u<TL, GTW, 4>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            if (s_first >= 3) chain_stage_u<TL, GTW, 3>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            if (s_first >= 2) chain_stage_u<TL, GTW, 2>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            if (s_first >= 1) chain_stage_u<TL, GTW, 1>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            chain_stage_u<TL, GTW, 0>(x, y, ex, lane, s_tw, tw_stride, log_m, a);
+            lds_st_u(s_data, TILE, ex, x);
+            lds_st_u(s_data, TILE, ex + 1, y);
+        }
+        __syncthreads();
+        return;
+    }
     if (!R4) {                                  // one stage per trip (default)
         for (; s >= 0; s--) {
             const int h = 1 << s;
@@ -348,7 +450,7 @@ __device__ __forceinline__ FrU load_u(const NttPassArgs &a, const Fr *in, size_t
     return x;                                 // canonical (< r), limbs < 2^29: a valid butterfly operand
 }
 
-template <int TL, bool GTW, bool R4>
+template <int TL, bool GTW, int R4>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) {
     constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -381,7 +483,7 @@ __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_cols_u(NttPassArgs a) 
     }
 }
 
-template <int TL, bool GTW, bool R4>
+template <int TL, bool GTW, int R4>
 __global__ void __launch_bounds__(NTT_THREADS_U) ntt_pass_rows_u(NttPassArgs a) {
     constexpr int TILE = 1 << TL;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -504,14 +606,17 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
                               reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, true>),
                               reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, true>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, true>),
                               reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, false>),
-                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, false>)})
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, false>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, 2>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, 2>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, 2>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, 2>)})
             ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     const bool uform = ctx->opt_ntt_mode != 0;          // 1 (default): unsaturated butterflies; 0: saturated (the first version)
-    const bool r4 = ctx->opt_ntt_radix != 2;
-    auto *k_cols = uform ? (r4 ? ntt_pass_cols_u<11, false, true> : ntt_pass_cols_u<11, false, false>) : ntt_pass_cols;
-    auto *k_rows = uform ? (r4 ? ntt_pass_rows_u<11, false, true> : ntt_pass_rows_u<11, false, false>) : ntt_pass_rows;
+    const bool r4 = ctx->opt_ntt_radix == 4;
+    const bool xch = ctx->opt_ntt_radix == 1;       // lane exchanges for the last stages
+    auto *k_cols = uform ? (xch ? ntt_pass_cols_u<11, false, 2> : r4 ? ntt_pass_cols_u<11, false, true> : ntt_pass_cols_u<11, false, false>) : ntt_pass_cols;
+    auto *k_rows = uform ? (xch ? ntt_pass_rows_u<11, false, 2> : r4 ? ntt_pass_rows_u<11, false, true> : ntt_pass_rows_u<11, false, false>) : ntt_pass_rows;
     const unsigned nthreads = uform ? NTT_THREADS_U : NTT_THREADS;
     if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
@@ -585,7 +690,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
         a.wu = t->wu.as<uint32_t>();
         a.log_n2 = 12;
         a.log_n1 = log_n - 12;
-        const size_t big_lds = (size_t)9 * 4 * 4096;
+        const size_t big_lds = (size_t)9 * 4 * 4096 + (xch ? 9 * 4 * 64 : 0);       // + the lane-exchange chain's 64 twiddles
         {
             NttPassArgs p1 = a;
             p1.in = data; p1.out = data;
@@ -593,7 +698,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p1.batch_stride = 0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (12 - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            if (r4) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            if (xch) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            else if (r4) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
             else hipLaunchKernelGGL((ntt_pass_cols_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
         }
         {
@@ -603,7 +709,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p2.post_const_on = post_const_on;
             const unsigned grid = (unsigned)((size_t)1 << a.log_n1);
             ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-            if (r4) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            if (xch) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            else if (r4) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
             else hipLaunchKernelGGL((ntt_pass_rows_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
         }
     } else if (log_n <= NTT_MAX_SUB_LOG) {
