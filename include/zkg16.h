@@ -350,7 +350,8 @@ ZKG16_API void zkg16_kernel_stats_reset(zkg16_ctx *ctx);
  *   "wm_concurrent"  0 = witness map in order on the main stream (default: own stream)  "fixup_aux"      1 = fix-ups on the reduction stream
  *   "g1_waves"       G1 accumulation waves per SIMD in the resident round (0 = 2)       "min_seg"        shortest per-lane run (0 = adaptive)
  *   "ntt_mode"       0 = saturated-limb butterflies (first version), 1 = unsaturated (default)
- *   "ntt_radix"      1 (default; also 0) = the last seven butterfly stages of a tile by lane exchanges, 2 = every stage through the LDS, 4 = two stages per LDS trip
+ *   "ntt_radix"      1 (default; also 0) = the last seven butterfly stages of a tile by lane exchanges, 3 = the top seven as well,
+ *                    2 = every stage through the LDS, 4 = two stages per LDS trip
  *   "fuse_pointwise" 1 (default) = (ab - c)/Z fused into the load of the seventh transform, 0 = its own pass
  *   "collect_threads" host combination of the z-side MSMs' window sums: 0 = own threads for plain keys, 1 = always, 2 = never
  *   "fixed_base_bits" window width of the setup's fixed-base multiplications (0 = by batch size; 16 / 18 / 20 = two-level tables)

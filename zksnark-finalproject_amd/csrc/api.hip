@@ -910,8 +910,8 @@ int set_option_one(zkg16_ctx *ctx, const char *name, int64_t value) {
         return ZKG16_OK;
     }
     if (!strcmp(name, "ntt_radix")) {          // 1 (default; also 0): the last seven stages by lane exchanges, the others one per LDS trip; 2: every stage through the LDS; 4: two per trip (radix 4)
-        if (value != 0 && value != 1 && value != 2 && value != 4) return ZKG16_ERR_BAD_ARG;
-        ctx->opt_ntt_radix = value == 4 ? 4 : value == 2 ? 2 : 1;
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4) return ZKG16_ERR_BAD_ARG;      // 3: the top seven stages by lane exchanges too
+        ctx->opt_ntt_radix = value == 0 ? 1 : (int)value;
         return ZKG16_OK;
     }
     if (!strcmp(name, "ntt_xcd")) {            // 1 (default): XCD-aware tile order in the NTT passes; 2 = off (0 restores the default)

@@ -312,14 +312,67 @@ __device__ __forceinline__ void chain_stage_u(FrU &x, FrU &y, int &ex, int lane,
     }
 }
 
+// stage Q (0 .. 6) of the UPPER chain (MODE 3): stage st = log_m - 1 - Q of the sub-transform; the lanes of a wave hold the pairs whose
+// index bits log_m - 2 .. log_m - 7 spell the lane number, so the partner of the next stage is lane ^ (32 >> Q)
+template <int TL, bool GTW, int Q>
+__device__ __forceinline__ void chain_stage_hi_u(FrU &x, FrU &y, int &ex, int lane, const uint32_t *s_tw, int tw_stride, int log_m, const NttPassArgs &a) {
+    const int st = log_m - 1 - Q;
+    const int j = ex & ((1 << st) - 1);
+    bfly_u<false>(x, y, tw_u<TL, GTW>(s_tw, tw_stride, j << Q, log_m, a));
+    if constexpr (Q < 6) {
+        const bool hi = (lane >> (5 - Q)) & 1;
+        FrU send;
+#pragma unroll
+        for (int k = 0; k < 9; k++) send.l[k] = hi ? x.l[k] : y.l[k];
+        const FrU recv = lane_xchg_u<(32 >> Q)>(send, lane);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (hi) x.l[k] = recv.l[k]; else y.l[k] = recv.l[k];
+        }
+        if (hi) ex += 1 << (st - 1);
+    }
+}
+
 template <int TL, bool GTW, int R4>
 __device__ __forceinline__ void lds_dif_u(uint32_t *s_data, const uint32_t *s_tw, int log_m, int tw_stride, const NttPassArgs &a) {
     constexpr int TILE = 1 << TL;
     const int tid = threadIdx.x;
     int s = log_m - 1;
-    if (R4 == 2) {
+    if (R4 == 2 || R4 == 3) {
         if (log_m < 1) return;                                   // a one-point sub-transform: nothing to do
-        const int s_first = log_m - 1 < 6 ? log_m - 1 : 6;      // stages s_first .. 0 in registers
+        int s_first = log_m - 1 < 6 ? log_m - 1 : 6;            // stages s_first .. 0 in registers
+        if (R4 == 3 && log_m >= 8 && log_m <= 14) {
+            // MODE 3: the TOP seven stages in registers as well (pairs dealt to the lanes by their upper index bits), ONE trip through
+            // the LDS, then the remaining log_m - 7 stages by the chain below
+            if (GTW && tid < 64) {
+                uint32_t *tws = const_cast<uint32_t *>(s_tw);
+                const unsigned nmask = (1u << a.log_n) - 1u;
+                unsigned idx = ((unsigned)tid << (log_m - 7)) << (a.log_n - log_m);
+                if (a.inverse) idx = ((1u << a.log_n) - idx) & nmask;
+                const uint32_t *t = a.wu + (size_t)idx * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) tws[k * 64 + tid] = t[k];
+            }
+            const int lane_a = tid & 63, lo_bits = log_m - 7;
+            for (int u = tid; u < TILE / 2; u += NTT_THREADS_U) {
+                const int rest = u >> 6;
+                const int c = rest >> lo_bits, p_lo = rest & ((1 << lo_bits) - 1);
+                int ex = (c << log_m) + (lane_a << lo_bits) + p_lo;
+                FrU x = lds_ld_u(s_data, TILE, ex), y = lds_ld_u(s_data, TILE, ex + (1 << (log_m - 1)));
+                chain_stage_hi_u<TL, GTW, 0>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 1>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 2>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 3>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 4>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 5>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                chain_stage_hi_u<TL, GTW, 6>(x, y, ex, lane_a, s_tw, tw_stride, log_m, a);
+                lds_st_u(s_data, TILE, ex, x);
+                lds_st_u(s_data, TILE, ex + (1 << (log_m - 7)), y);
+            }
+            __syncthreads();
+            s = log_m - 8;
+            s_first = s;                                         // (<= 6) the rest is the lower chain, no LDS stage in between
+        }
         if (GTW && tid < 64) {          // (log_m >= 11 on this path) the chain's twiddles, read once per block instead of once per butterfly
             uint32_t *tws = const_cast<uint32_t *>(s_tw);
             const unsigned nmask = (1u << a.log_n) - 1u;
@@ -608,15 +661,18 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
                               reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, false>),
                               reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, false>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, false>),
                               reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, 2>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, 2>),
-                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, 2>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, 2>)})
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, 2>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, 2>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<12, true, 3>), reinterpret_cast<const void *>(ntt_pass_rows_u<12, true, 3>),
+                              reinterpret_cast<const void *>(ntt_pass_cols_u<11, false, 3>), reinterpret_cast<const void *>(ntt_pass_rows_u<11, false, 3>)})
             ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     const bool uform = ctx->opt_ntt_mode != 0;          // 1 (default): unsaturated butterflies; 0: saturated (the first version)
     const bool r4 = ctx->opt_ntt_radix == 4;
     const bool xch = ctx->opt_ntt_radix == 1;       // lane exchanges for the last stages
-    auto *k_cols = uform ? (xch ? ntt_pass_cols_u<11, false, 2> : r4 ? ntt_pass_cols_u<11, false, true> : ntt_pass_cols_u<11, false, false>) : ntt_pass_cols;
-    auto *k_rows = uform ? (xch ? ntt_pass_rows_u<11, false, 2> : r4 ? ntt_pass_rows_u<11, false, true> : ntt_pass_rows_u<11, false, false>) : ntt_pass_rows;
+    const bool xch2 = ctx->opt_ntt_radix == 3;      // ... and for the top seven stages
+    auto *k_cols = uform ? (xch2 ? ntt_pass_cols_u<11, false, 3> : xch ? ntt_pass_cols_u<11, false, 2> : r4 ? ntt_pass_cols_u<11, false, true> : ntt_pass_cols_u<11, false, false>) : ntt_pass_cols;
+    auto *k_rows = uform ? (xch2 ? ntt_pass_rows_u<11, false, 3> : xch ? ntt_pass_rows_u<11, false, 2> : r4 ? ntt_pass_rows_u<11, false, true> : ntt_pass_rows_u<11, false, false>) : ntt_pass_rows;
     const unsigned nthreads = uform ? NTT_THREADS_U : NTT_THREADS;
     if (log_n > 3 * NTT_MAX_SUB_LOG - 2) throw HipError{hipErrorInvalidValue, "ntt: domain above build limit 2^31", __FILE__, __LINE__};
     NttTables *t = ntt_get_tables(ctx, log_n);
@@ -690,7 +746,7 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
         a.wu = t->wu.as<uint32_t>();
         a.log_n2 = 12;
         a.log_n1 = log_n - 12;
-        const size_t big_lds = (size_t)9 * 4 * 4096 + (xch ? 9 * 4 * 64 : 0);       // + the lane-exchange chain's 64 twiddles
+        const size_t big_lds = (size_t)9 * 4 * 4096 + ((xch || xch2) ? 9 * 4 * 64 : 0);       // + the lane-exchange chain's 64 twiddles
         {
             NttPassArgs p1 = a;
             p1.in = data; p1.out = data;
@@ -698,7 +754,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p1.batch_stride = 0;
             const unsigned grid = (unsigned)(((size_t)1 << a.log_n2) >> (12 - a.log_n1));
             ScopedKernelTimer kt(ctx, "ntt_pass_cols", (double)n);
-            if (xch) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            if (xch2) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, 3>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
+            else if (xch) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
             else if (r4) hipLaunchKernelGGL((ntt_pass_cols_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
             else hipLaunchKernelGGL((ntt_pass_cols_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p1);
         }
@@ -709,7 +766,8 @@ Fr *ntt_run(zkg16_ctx *ctx, Fr *data, Fr *tmp, int log_n, bool inverse, bool cos
             p2.post_const_on = post_const_on;
             const unsigned grid = (unsigned)((size_t)1 << a.log_n1);
             ScopedKernelTimer kt(ctx, "ntt_pass_rows", (double)n);
-            if (xch) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            if (xch2) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, 3>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
+            else if (xch) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, 2>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
             else if (r4) hipLaunchKernelGGL((ntt_pass_rows_u<12, true, true>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
             else hipLaunchKernelGGL((ntt_pass_rows_u<12, true, false>), dim3(grid), dim3(NTT_THREADS_U), big_lds, ctx->stream, p2);
         }
