@@ -166,6 +166,14 @@ def test_native_g1_decompression_equals_python_rules():
     assert np.array_equal(pts[0], wire.g1_decompress(bytes(torsion), validate=False)[0])
     with pytest.raises(ValueError):
         wire.g1_decompress_many(good, 2)                                 # length does not match the count
+    # 130 points: the library splits them over helper threads; one bad point among them must still be found
+    many = [encs[i % 40] for i in range(130)]
+    got, ginf = wire.g1_decompress_many(b"".join(many), 130)
+    assert all(np.array_equal(got[i], got[i % 40]) for i in range(130)) and not ginf.any()
+    many[97] = bytes(torsion)
+    with pytest.raises(ValueError) as e:
+        wire.g1_decompress_many(b"".join(many), 130)
+    assert "97" in str(e.value)
 
 
 def test_native_codecs_equal_python_rules():

@@ -16,6 +16,10 @@
 //     which leaves pairing-product equations unchanged.
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/zkg16.h"
@@ -669,11 +673,41 @@ bool fq2_sqrt(const Fq64 &a0, const Fq64 &a1, Fq64 &c0, Fq64 &c1) {
 // the lexicographically larger root) -> affine Montgomery limbs, strict as `G1Affine::deserialize_compressed`.  status[i]: 0 ok,
 // 1 not a compressed encoding, 2 non-canonical infinity, 3 x not reduced, 4 x not on the curve, 5 not in the prime-order subgroup
 // (only with validate).  Returns ZKG16_OK when every point decoded.
+static int g1_decompress_range(const uint8_t *bytes, size_t lo, size_t hi, uint64_t *out, uint8_t *inf, int validate, int *status);
+
 int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *inf, int validate, int *status) {
     if ((!bytes || !out || !inf) && n) return ZKG16_ERR_BAD_ARG;
+    (void)fq_consts();
+    (void)pf::endo();                // the function-local statics exist before any helper thread asks for them
+    // a square root (~20 us) and a subgroup test (~50 us) per point: the 258 points of a prime-handler key on up to eight threads
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = n >= 64 && hw > 1 ? std::min<size_t>(std::min<size_t>(8, hw), n / 16) : 1;
+    if (nthreads <= 1) return g1_decompress_range(bytes, 0, n, out, inf, validate, status) ? ZKG16_ERR_BAD_ARG : ZKG16_OK;
+    std::atomic<int> bad{0};
+    {
+        struct Joiner {          // helper threads joined on every exit path; one that cannot be started runs inline
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+        } tg;
+        const size_t per = (n + nthreads - 1) / nthreads;
+        for (size_t t = 0; t < nthreads; t++) {
+            const size_t lo = t * per, hi = std::min(n, lo + per);
+            if (lo >= hi) break;
+            auto job = [=, &bad] { bad += g1_decompress_range(bytes, lo, hi, out, inf, validate, status); };
+            try {
+                tg.th.emplace_back(job);
+            } catch (const std::system_error &) {
+                job();
+            }
+        }
+    }
+    return bad.load() ? ZKG16_ERR_BAD_ARG : ZKG16_OK;
+}
+
+static int g1_decompress_range(const uint8_t *bytes, size_t lo_k, size_t hi_k, uint64_t *out, uint8_t *inf, int validate, int *status) {
     const FqConsts &kc = fq_consts();
     int bad = 0;
-    for (size_t k = 0; k < n; k++) {
+    for (size_t k = lo_k; k < hi_k; k++) {
         const uint8_t *b = bytes + 48 * k;
         uint64_t *o = out + 12 * k;
         int st = 0;
@@ -702,7 +736,7 @@ int zkg16_g1_decompress(const uint8_t *bytes, size_t n, uint64_t *out, uint8_t *
         if (status) status[k] = st;
         if (st) bad++;
     }
-    return bad ? ZKG16_ERR_BAD_ARG : ZKG16_OK;
+    return bad;
 }
 
 // the same for G2: 96 bytes = x.c1 || x.c0 big-endian, y compared as (c1, c0); out = n x 24 limbs (x.c0, x.c1, y.c0, y.c1)
