@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import wire
-from .circuits import fibonacci_circuit, matrix_circuit, prime_circuit, prime_circuit_handle, prime_public_inputs, prime_search
+from .circuits import fibonacci_circuit, fibonacci_circuit_handle, matrix_circuit, prime_circuit, prime_circuit_handle, prime_public_inputs, prime_search
 from .workloads import R_MOD, g1_generator, g2_generator
 
 
@@ -155,7 +155,7 @@ def prove_matrix(dev, size, matrix_a, matrix_b, seed=0, keep_key=False):
 
 def prove_fibonacci(dev, a, b, num_of_rounds, seed=42, keep_key=False):
     """-> the reference's OutputDataFib-like fields (fibbonaci_handler.rs:84-90)."""
-    circ = fibonacci_circuit(a, b, num_of_rounds)
+    circ = fibonacci_circuit(a, b, num_of_rounds) if keep_key else fibonacci_circuit_handle(a, b, num_of_rounds)
     out = _setup_and_prove(dev, circ, random.Random(seed), keep_key)
     return dict(proof=wire.encode_proof(out["proof"], out["inf"]), proving_time=out["proving_time"], setup_time=out["setup_time"],
                 num_constraints=circ.num_constraints, num_variables=circ.num_instance,
