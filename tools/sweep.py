@@ -1,6 +1,7 @@
 """In-process counterpart of the reference's sweep drivers (bench/matrix.py:10-60: all-ones matrices of size 2^k, prove
 then verify; bench/fibo.py:26-60: Fibonacci rounds 0..186 with a = 0, b = 1), through the handler mirrors instead of
-HTTP.  Records the reference's fields: num_constraints, setup_time, proving_time, verifying_time (seconds).
+HTTP.  Records the reference's fields: num_constraints, setup_time, proving_time, verifying_time (seconds) of the SECOND request of
+every size (the first one of a size in a process also builds that domain's NTT tables and grows the workspaces).
 bench/prime.py:17-70: random x of 2, 4, .. 64 bits, i = 32 candidates, retried until a prime is found, prove then verify
 with the returned pvk.
     python tools/sweep.py matrix [max_power=6] [warm]   |   python tools/sweep.py fib [step=31]   |   python tools/sweep.py prime [per_size=2]"""
@@ -22,7 +23,9 @@ if kind == "matrix":
     for k in range(1, top + 1):
         n = 1 << k
         ones = np.ones((n, n), dtype=np.uint64)
-        t0 = time.perf_counter()
+        if n < (1 << top) or not (len(sys.argv) > 3 and sys.argv[3] == "warm"):
+            handlers.prove_matrix(dev, n, ones, ones, seed=100 + k)      # the first request of a size also builds that domain's NTT tables and
+        t0 = time.perf_counter()                                       # grows the workspaces: the server's steady state is the second one
         res = handlers.prove_matrix(dev, n, ones, ones, seed=k)
         t1 = time.perf_counter()
         v = handlers.verify_proof(res["pvk"], res["_circuit"].public_inputs, res["proof"])      # the prepared key, as the reference's verify handler
